@@ -1,0 +1,131 @@
+/*
+ * swn_hip.h  --  C ABI of the MI355X (gfx950) shallow-WaveNet hot path.
+ *
+ * The reference (patrickltobing/shallow-wavenet) has no native code and no FFI: its hot
+ * path is the PyTorch module code of src/nets/{cswnv_shift1,dswnv}.py.  This header is the
+ * boundary a maintainer would bind from those modules (see INTEGRATION.md for the ctypes
+ * stub); every entry point cites the reference lines it replaces.
+ *
+ * Conventions
+ *   - plain C: pointers, sizes, a POD descriptor; no torch / C++ types.
+ *   - `*_dev` pointers are device (HBM) addresses, `*_host` pointers host addresses.
+ *   - all tensors fp32, contiguous, channels-first (B, C, T) exactly as the reference
+ *     holds them; integer data (mu-law indices) are int32 on the device.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Launches are
+ *     asynchronous; nothing in here synchronises, allocates or frees device memory.
+ *   - every function returns 0 on success or a negative SWN_E_* code;
+ *     swn_strerror() maps it to text.  No global mutable state.
+ */
+#ifndef SWN_HIP_H
+#define SWN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWN_ABI_VERSION 1
+
+#define SWN_KIND_LAPLACE 0   /* CSWNV, cswnv_shift1.py:130 */
+#define SWN_KIND_SOFTMAX 1   /* DSWNV, dswnv.py:190       */
+
+#define SWN_OK            0
+#define SWN_E_BADDESC    -1  /* descriptor outside what the kernels support            */
+#define SWN_E_BADARG     -2  /* null pointer / size mismatch                           */
+#define SWN_E_LAUNCH     -3  /* HIP reported a launch error (hipGetLastError)          */
+#define SWN_E_UNSUPPORTED -4 /* valid reference configuration not built yet            */
+#define SWN_E_NODEVICE   -5
+
+/* Constructor arguments of CSWNV / DSWNV (cswnv_shift1.py:131-133, dswnv.py:191-193). */
+typedef struct swn_net_desc {
+    int32_t kind;              /* SWN_KIND_*                                  */
+    int32_t n_aux;
+    int32_t hid_chn;
+    int32_t skip_chn;
+    int32_t aux_kernel_size;
+    int32_t aux_dilation_size;
+    int32_t dilation_depth;
+    int32_t dilation_repeat;
+    int32_t kernel_size;
+    int32_t upsampling_factor;
+    int32_t seg;               /* laplace only, 1 for softmax                 */
+    int32_t lpc;               /* laplace only                                */
+    int32_t n_quantize;        /* softmax only                                */
+    int32_t wav_conv_flag;
+    int32_t audio_in_flag;     /* softmax only                                */
+    int32_t aux_conv2d_flag;   /* laplace only (not built: SWN_E_UNSUPPORTED) */
+} swn_net_desc;
+
+/* ---- introspection --------------------------------------------------------------- */
+int         swn_abi_version(void);
+const char* swn_strerror(int code);
+/* number of HIP devices visible, or a negative SWN_E_* */
+int         swn_device_count(void);
+/* receptive field / number of state_dict tensors, as CSWNV.__init__ computes them
+ * (cswnv_shift1.py:170-183).  Negative on a bad descriptor. */
+int         swn_receptive_field(const swn_net_desc* d);
+int         swn_num_tensors(const swn_net_desc* d);
+
+/* ---- parameter packing (host side) ---------------------------------------------------
+ * Re-lays the reference state_dict (tensors given in state_dict order, fp32 host pointers,
+ * reference shapes: SURVEY.md 8b) into one flat fp32 buffer the kernels stream from:
+ * tap-major dilated-conv rows, fused wav_conv+causal taps, the skip 1x1s concatenated, the
+ * in_x 1x1s stacked for the frame-rate GEMM, summed biases.  The packed buffer is what is
+ * uploaded once and broadcast over RCCL (decode_cswnv_laplace-shift1.py:223-224 loads the
+ * checkpoint per process instead). */
+size_t swn_packed_floats(const swn_net_desc* d);
+int    swn_pack_params(const swn_net_desc* d, const float* const* tensors_host, int n_tensors,
+                       float* packed_host, size_t packed_floats);
+
+/* ---- frame-rate front end  (cswnv_shift1.py:193,297 / dswnv.py:252,302) ---------------
+ * scale_in -> conv_aux (two-sided dilated k=3 stack) -> hoisted in_x:
+ *   cond[b][f][l][s][o] = sum_c in_x[l].weight[o, c*seg+s] * conv_aux(scale_in(aux))[b,c,f]
+ * The rank-1 upsampling (ConvTranspose2d (1,U), cswnv_shift1.py:37-65) is folded into the
+ * consumers as  in_x(x)[o,t] = bx[l][o] + sum_s w_up[(t+s)%U] * cond[b][(t+s)/U][l][s][o].
+ *   aux_dev   (B, n_aux, Tf)             in
+ *   work_dev  swn_frontend_work_floats() scratch
+ *   cond_dev  (B, Tf, L*seg*2H)          out                                            */
+size_t swn_frontend_work_floats(const swn_net_desc* d, int batch, int n_frames);
+size_t swn_cond_floats(const swn_net_desc* d, int batch, int n_frames);
+int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float* aux_dev,
+                    int batch, int n_frames, float* work_dev, float* cond_dev, void* stream);
+
+/* ---- autoregressive decode  (CSWNV.batch_fast_generate cswnv_shift1.py:287-430,
+ *                              DSWNV.batch_fast_generate dswnv.py:296-399) ---------------
+ * One persistent workgroup per utterance runs prologue (rf+1 seed positions) and all
+ * n_steps steps; all utterances run n_steps = max(n_samples)/seg steps like the reference.
+ *   cond_dev    (B, Tf, L*seg*2H)  from swn_frontend
+ *   noise_dev   laplace: (B, n_steps, seg) uniform(-0.4999,0.5) draws; softmax: (B, n_steps, Q)
+ *               Exp(1) draws  (host generates them in the reference's draw order)
+ *   forced_dev  optional teacher forcing (may be NULL): laplace (B, n_steps*seg) fp32 samples,
+ *               softmax (B, n_steps) int32 indices fed back instead of the generated ones
+ *   state_dev   swn_decode_state_floats() scratch (history rings; zeroed by the call)
+ *   out_dev     laplace: (B, n_steps*seg) fp32 ; softmax: (B, n_steps) int32
+ *   heads_dev   optional (B, n_steps, n_out) raw out_2 outputs at each step (may be NULL)
+ *   variant     0 = auto, 1 = generic kernel, 2 = register/LDS-resident BL6-class kernel   */
+size_t swn_decode_state_floats(const swn_net_desc* d, int batch);
+int    swn_decode(const swn_net_desc* d, const float* packed_dev, const float* cond_dev,
+                  int batch, int n_frames, int n_steps, const float* noise_dev,
+                  const void* forced_dev, float* state_dev, void* out_dev, float* heads_dev,
+                  int variant, void* stream);
+
+/* ---- teacher-forced stack  (CSWNV.forward cswnv_shift1.py:191-267,
+ *                             DSWNV.forward dswnv.py:250-276) ----------------------------
+ *   audio_dev   laplace: (B, 1, T - seg) fp32 samples ; softmax: (B, T - 1) int32 indices
+ *               (the one-hot of dswnv.py:68-93 is never materialised)
+ *   cond_dev    (B, Tf, L*seg*2H) from swn_frontend, T = Tf * U
+ *   work_dev    swn_forward_work_floats() scratch (hidden states, skip accumulator)
+ *   out_dev     (B, n_out, Tp) raw out_2 outputs, Tp = T - 2*seg + 1 (softmax: T - 1);
+ *               the host splits mu / log b / a (cswnv_shift1.py:228-267)
+ *   hs_dev      optional (L+1, B, H, Tp) hidden states h_0..h_L for backward / tests      */
+size_t swn_forward_work_floats(const swn_net_desc* d, int batch, int n_frames);
+int    swn_forward(const swn_net_desc* d, const float* packed_dev, const float* cond_dev,
+                   const void* audio_dev, int batch, int n_frames, float* work_dev,
+                   float* out_dev, float* hs_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWN_HIP_H */

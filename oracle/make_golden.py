@@ -1,0 +1,309 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ by IMPORTING the reference.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  It imports the reference's own `src/nets/{cswnv_shift1,dswnv}.py` unmodified,
+loads weights from the deterministic formula of `shallow_wavenet_amd.synth` (weights are
+never stored), runs `forward` / `batch_fast_generate` on CPU while recording every noise
+draw, and writes small .npz files holding inputs, noise and expected outputs only.
+
+Harness-side shims (the reference files are not touched):
+  * `torch.Tensor.cuda` -> identity, because cswnv_shift1.py:345,347 call .cuda()
+    unconditionally and there is no GPU here (ordinary RuntimeError otherwise);
+  * `torch.Tensor.uniform_` wrapped during generate to record the Laplace noise;
+  * a forward hook on `out_2` records the per-step head outputs.
+
+Usage:  python oracle/make_golden.py [--only NAME_SUBSTR] [--skip-big]
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, "/root/reference/src/nets")
+sys.dont_write_bytecode = True
+
+import cswnv_shift1 as ref_c   # noqa: E402  (the reference itself)
+import dswnv as ref_d          # noqa: E402
+
+from shallow_wavenet_amd import config as C            # noqa: E402
+from shallow_wavenet_amd.synth import synth_state_dict, synth_aux   # noqa: E402
+from oracle import cpu_ref                               # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+torch.Tensor.cuda = lambda self, *a, **k: self          # shim, see module docstring
+
+
+def build_ref(cfg: C.NetConfig, seed: int, flavor: str):
+    mod = ref_d.DSWNV if cfg.kind == "softmax" else ref_c.CSWNV
+    m = mod(**cfg.ctor_kwargs())
+    sd = synth_state_dict(cfg, seed=seed, flavor=flavor)
+    ref_sd = m.state_dict()
+    assert list(ref_sd.keys()) == list(sd.keys()), (list(ref_sd.keys()), list(sd.keys()))
+    for k in sd:
+        assert tuple(ref_sd[k].shape) == sd[k].shape, (k, ref_sd[k].shape, sd[k].shape)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.eval()
+    assert m.receptive_field == cfg.receptive_field
+    assert list(m.padding) == cfg.paddings
+    return m, sd
+
+
+def ragged_aux(cfg, frames, seed):
+    """zero-padded in raw feature space like pad_list (decode_cswnv...py:30-48,104)."""
+    B, Tf = len(frames), max(frames)
+    aux = synth_aux(cfg, B, Tf, seed=seed)
+    for b, f in enumerate(frames):
+        aux[b, :, f:] = 0.0
+    return aux
+
+
+def digest(a: np.ndarray) -> np.ndarray:
+    a = np.asarray(a, dtype=np.float64).ravel()
+    return np.array([a.sum(), np.abs(a).sum(), (a * a).sum()] + list(a[:8]) + [0.0] * max(0, 8 - a.size))
+
+
+def gen_laplace(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, with_forward=True,
+                with_grads=False, solo_of=None):
+    t0 = time.time()
+    m, sd = build_ref(cfg, wseed, flavor)
+    aux = ragged_aux(cfg, frames, aux_seed)
+    n_samples = [f * cfg.U for f in frames]
+    B = len(frames)
+
+    rec, heads = [], []
+    orig_uniform = torch.Tensor.uniform_
+
+    def rec_uniform(self, *a, **k):
+        r = orig_uniform(self, *a, **k)
+        rec.append(self.detach().clone())
+        return r
+
+    hook = m.out_2.register_forward_hook(lambda mod, i, o: heads.append(o.detach()[:, :, -1].clone()))
+    torch.manual_seed(noise_seed)
+    torch.Tensor.uniform_ = rec_uniform
+    try:
+        samples = m.batch_fast_generate(torch.zeros(B, cfg.seg), torch.from_numpy(aux), n_samples, 4410)
+    finally:
+        torch.Tensor.uniform_ = orig_uniform
+        hook.remove()
+    n_steps = len(heads)
+    if cfg.lpc > 0:
+        noise = torch.stack(rec).reshape(n_steps, cfg.seg, B).permute(0, 2, 1).contiguous().numpy()
+    else:
+        noise = torch.stack(rec).reshape(n_steps, B, cfg.seg).numpy()
+    # the host-side generator must reproduce the captured stream
+    g = torch.Generator().manual_seed(noise_seed)
+    regen = cpu_ref.laplace_noise(cfg, n_steps, B, generator=g)
+    assert np.array_equal(regen, noise), "host noise order does not match the reference draw order"
+
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, flavor=np.array(flavor),
+               frames=np.array(frames), aux=aux, noise_seed=noise_seed, noise=noise,
+               heads=torch.stack(heads).numpy(), n_samples=np.array(n_samples))
+    for b in range(B):
+        out[f"samples_{b}"] = samples[b].astype(np.float32)
+
+    if with_forward:
+        T = max(frames) * cfg.U
+        rng = np.random.Generator(np.random.PCG64([aux_seed, 5]))
+        audio = rng.uniform(-0.9, 0.9, size=(B, 1, T - cfg.seg)).astype(np.float32)
+        for p in m.parameters():
+            p.requires_grad_(with_grads)
+        res = m(torch.from_numpy(aux), torch.from_numpy(audio), do=False, clip=False)
+        out["fwd_audio"] = audio
+        for i, r in enumerate(res):
+            out[f"fwd_{i}"] = r.detach().numpy()
+        resc = m(torch.from_numpy(aux), torch.from_numpy(audio), do=False, clip=True)
+        out["fwd_clip_n"] = len(resc)
+        if with_grads:
+            mu, b, log_b = res[0], res[1], res[2]
+            tgt = torch.from_numpy(rng.uniform(-0.9, 0.9, size=tuple(mu.shape)).astype(np.float32))
+            loss = ref_c.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
+            if cfg.lpc > 0:
+                loss = loss + 0.1 * res[3].pow(2).mean()
+            loss.backward()
+            out["loss_target"] = tgt.numpy()
+            out["loss"] = np.float64(loss.item())
+            for k, p in m.named_parameters():
+                gnp = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+                out[f"gdig_{k}"] = digest(gnp)
+                if gnp.size <= 4096:
+                    out[f"grad_{k}"] = gnp
+    if solo_of is not None:
+        # G4: utterance `solo_of` decoded alone with its own rows of the same noise
+        f1 = [frames[solo_of]]
+        aux1 = aux[solo_of:solo_of + 1, :, : f1[0]].copy()
+        rows = noise[: int(n_samples[solo_of] / cfg.seg), solo_of:solo_of + 1]
+        P = cpu_ref.as_params(sd)
+        solo = cpu_ref.laplace_generate(cfg, P, torch.from_numpy(aux1), [n_samples[solo_of]], rows)
+        out["solo_index"] = solo_of
+        out["solo_samples"] = solo[0]
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: steps={n_steps} B={B} {time.time() - t0:.1f}s "
+          f"|s|max={max(np.abs(s).max() for s in samples):.3f}")
+
+
+def gen_softmax(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, head_stride=1,
+                with_forward=True, with_grads=False):
+    t0 = time.time()
+    m, sd = build_ref(cfg, wseed, flavor)
+    aux = ragged_aux(cfg, frames, aux_seed)
+    n_samples = [f * cfg.U for f in frames]
+    B, Q = len(frames), cfg.n_quantize
+    heads = []
+    hook = m.out_2.register_forward_hook(lambda mod, i, o: heads.append(o.detach()[:, :, -1].clone()))
+    torch.manual_seed(noise_seed)
+    try:
+        samples = m.batch_fast_generate(torch.full((B, 1), Q // 2, dtype=torch.int64),
+                                        torch.from_numpy(aux), n_samples, 4410)
+    finally:
+        hook.remove()
+    n_steps = len(heads)
+    heads = torch.stack(heads).numpy()
+    g = torch.Generator().manual_seed(noise_seed)
+    q = cpu_ref.softmax_noise(cfg, n_steps, B, generator=g)
+    # the regenerated Exp(1) stream must reproduce the reference's indices from its own logits
+    idx, margin = cpu_ref.categorical_from_noise(torch.from_numpy(heads), torch.from_numpy(q))
+    ref_idx = np.stack([np.pad(s, (0, n_steps - len(s))) for s in samples], 1)
+    for b in range(B):
+        n = n_samples[b]
+        assert np.array_equal(idx.numpy()[:n, b], ref_idx[:n, b]), "Exp(1) stream mismatch"
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, flavor=np.array(flavor),
+               frames=np.array(frames), aux=aux, noise_seed=noise_seed,
+               q_sha=np.array(hashlib.sha256(q.tobytes()).hexdigest()),
+               heads=heads[::head_stride], head_stride=head_stride,
+               margin=margin.numpy().astype(np.float32), n_samples=np.array(n_samples))
+    if q.nbytes <= (1 << 20):
+        out["q"] = q
+    for b in range(B):
+        out[f"samples_{b}"] = samples[b].astype(np.int64)
+    if with_forward:
+        T = max(frames) * cfg.U
+        rng = np.random.Generator(np.random.PCG64([aux_seed, 5]))
+        idx_in = rng.integers(0, Q, size=(B, T - 1)).astype(np.int64)
+        oh = ref_d.OneHot(torch.from_numpy(idx_in), Q).transpose(1, 2)
+        for p in m.parameters():
+            p.requires_grad_(with_grads)
+        logits = m(oh, torch.from_numpy(aux))
+        out["fwd_audio_idx"] = idx_in
+        out["fwd_logits_dig"] = digest(logits.detach().numpy())
+        out["fwd_logits_head"] = logits.detach().numpy()[:, :64]
+        out["fwd_logits_tail"] = logits.detach().numpy()[:, -64:]
+        if with_grads:
+            tgt = torch.from_numpy(rng.integers(0, Q, size=(B, T - 1)).astype(np.int64))
+            loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, Q), tgt.reshape(-1))
+            loss.backward()
+            out["loss_target"] = tgt.numpy()
+            out["loss"] = np.float64(loss.item())
+            for k, p in m.named_parameters():
+                gnp = p.grad.numpy()
+                out[f"gdig_{k}"] = digest(gnp)
+                if gnp.size <= 4096:
+                    out[f"grad_{k}"] = gnp
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: steps={n_steps} B={B} {time.time() - t0:.1f}s "
+          f"min margin={margin.min():.2e}")
+
+
+def gen_numerics():
+    """G3: mu-law tables, Laplace transform grid, geometry and state-dict listings."""
+    out = {}
+    idx = np.arange(256)
+    out["mulaw_decode_256"] = ref_d.decode_mu_law(idx, 256)
+    sweep = np.linspace(-1.0, 1.0, 4001)
+    out["mulaw_sweep"] = sweep
+    out["mulaw_encode_sweep"] = ref_d.encode_mu_law(sweep, 256)
+    out["mulaw_roundtrip"] = ref_d.encode_mu_law(ref_d.decode_mu_law(idx, 256), 256)
+    eps = torch.linspace(-0.4999, 0.5, 2001)[:-1]
+    out["lap_eps"] = eps.numpy()
+    out["lap_t"] = (-eps.sign() * torch.log1p(-2 * eps.abs())).numpy()
+    oh = ref_d.OneHot(torch.tensor([[0, 255, 256, 511, -1, 128]]), 256)
+    out["onehot_argmax"] = oh.argmax(-1).numpy()
+    listing = []
+    for nm, cfg in [("bl6_laplace", C.bl6_laplace()), ("bl6_laplace_s5l4", C.bl6_laplace(5, 4)),
+                    ("bl6_softmax", C.bl6_softmax()), ("ref6_laplace", C.ref6_laplace()),
+                    ("ref6_laplace_s5", C.ref6_laplace(5, 4)), ("ref6_softmax", C.ref6_softmax()),
+                    ("tiny_laplace", C.tiny()), ("tiny_softmax", C.tiny("softmax", wav_conv_flag=False))]:
+        mod = ref_d.DSWNV if cfg.kind == "softmax" else ref_c.CSWNV
+        m = mod(**cfg.ctor_kwargs())
+        keys = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        listing.append(repr(dict(name=nm, rf=m.receptive_field, padding=list(m.padding),
+                                 n_params=sum(p.numel() for p in m.parameters()), keys=keys)))
+    out["geometry"] = np.array(listing)
+    np.savez_compressed(os.path.join(GOLD, "g3_numerics.npz"), **out)
+    print("[golden] g3_numerics")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--skip-big", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(1)
+    jobs = []
+    # ---- G0 tiny, B=2 ragged, Tf=(8,6)
+    for seg, lpc in [(1, 0), (1, 4), (5, 4), (5, 0), (2, 4)]:
+        for fl in ("xavier", "trained"):
+            jobs.append((f"g0_tiny_lap_s{seg}l{lpc}_{fl}", gen_laplace,
+                         dict(cfg=C.tiny("laplace", seg, lpc), frames=[8, 6], wseed=11, flavor=fl,
+                              aux_seed=3, noise_seed=5, with_grads=(fl == "xavier"),
+                              solo_of=(1 if (seg, lpc) in ((1, 0), (5, 4)) else None))))
+    jobs.append(("g0_tiny_lap_nowav_s1l0", gen_laplace,
+                 dict(cfg=C.tiny("laplace", 1, 0, wav_conv_flag=False), frames=[8, 6], wseed=12,
+                      flavor="trained", aux_seed=3, noise_seed=6, with_grads=True)))
+    jobs.append(("g0_tiny_softmax", gen_softmax,
+                 dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[8, 6], wseed=13,
+                      flavor="xavier", aux_seed=3, noise_seed=7, with_grads=True)))
+    jobs.append(("g0_tiny_softmax_wav", gen_softmax,
+                 dict(cfg=C.tiny("softmax", wav_conv_flag=True), frames=[8, 6], wseed=14,
+                      flavor="xavier", aux_seed=3, noise_seed=8, with_grads=False)))
+    # ---- G1 BL6 (BASELINE-literal)
+    for fl in ("xavier", "trained"):
+        jobs.append((f"g1_bl6_lap_s1l0_b1_{fl}", gen_laplace,
+                     dict(cfg=C.bl6_laplace(1, 0), frames=[4], wseed=21, flavor=fl, aux_seed=4,
+                          noise_seed=9, with_forward=True)))
+    jobs.append(("g1_bl6_lap_s1l0_b3_trained", gen_laplace,
+                 dict(cfg=C.bl6_laplace(1, 0), frames=[4, 3, 2], wseed=21, flavor="trained",
+                      aux_seed=5, noise_seed=10, with_forward=False, solo_of=2)))
+    jobs.append(("g1_bl6_lap_s5l4_b1_trained", gen_laplace,
+                 dict(cfg=C.bl6_laplace(5, 4), frames=[4], wseed=22, flavor="trained", aux_seed=4,
+                      noise_seed=11, with_forward=True)))
+    jobs.append(("g1_bl6_lap_s5l4_b3_xavier", gen_laplace,
+                 dict(cfg=C.bl6_laplace(5, 4), frames=[4, 3, 2], wseed=22, flavor="xavier",
+                      aux_seed=5, noise_seed=12, with_forward=False)))
+    jobs.append(("g1_bl6_softmax_b1", gen_softmax,
+                 dict(cfg=C.bl6_softmax(), frames=[5], wseed=23, flavor="xavier", aux_seed=4,
+                      noise_seed=13)))
+    jobs.append(("g1_bl6_softmax_b3", gen_softmax,
+                 dict(cfg=C.bl6_softmax(), frames=[5, 4, 2], wseed=23, flavor="xavier", aux_seed=5,
+                      noise_seed=14, with_forward=False, head_stride=4)))
+    # ---- G2 REF6 (reference-shipped shape), 2*rf+220 steps
+    if not args.skip_big:
+        jobs.append(("g2_ref6_lap_s1l4_b1", gen_laplace,
+                     dict(cfg=C.ref6_laplace(1, 4), frames=[15], wseed=31, flavor="trained",
+                          aux_seed=6, noise_seed=15, with_forward=False)))
+        jobs.append(("g2_ref6_lap_s5l4_b2", gen_laplace,
+                     dict(cfg=C.ref6_laplace(5, 4), frames=[15, 12], wseed=32, flavor="trained",
+                          aux_seed=6, noise_seed=16, with_forward=False)))
+        jobs.append(("g2_ref6_softmax_b1", gen_softmax,
+                     dict(cfg=C.ref6_softmax(), frames=[14], wseed=33, flavor="xavier", aux_seed=6,
+                          noise_seed=17, with_forward=False, head_stride=8)))
+    for name, fn, kw in jobs:
+        if args.only and args.only not in name:
+            continue
+        fn(name, **kw)
+    if not args.only or "g3" in args.only:
+        gen_numerics()
+
+
+if __name__ == "__main__":
+    main()
