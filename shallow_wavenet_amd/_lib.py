@@ -1,0 +1,100 @@
+"""ctypes binding of the C ABI in include/swn_hip.h (libswn_hip.so, built in-tree by
+csrc/Makefile with hipcc --offload-arch=gfx950).
+
+There is deliberately no fallback: if the library cannot be loaded the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+import threading
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+from .config import NetConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswn_hip.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+_lock = threading.Lock()
+_lib = None
+
+
+class NetDesc(ctypes.Structure):
+    """mirror of `swn_net_desc` (include/swn_hip.h)."""
+    _fields_ = [(n, c_int32) for n in (
+        "kind", "n_aux", "hid_chn", "skip_chn", "aux_kernel_size", "aux_dilation_size",
+        "dilation_depth", "dilation_repeat", "kernel_size", "upsampling_factor", "seg", "lpc",
+        "n_quantize", "wav_conv_flag", "audio_in_flag", "aux_conv2d_flag")]
+
+
+def desc_from_cfg(cfg: NetConfig) -> NetDesc:
+    soft = cfg.kind == "softmax"
+    return NetDesc(kind=1 if soft else 0, n_aux=cfg.n_aux, hid_chn=cfg.hid_chn, skip_chn=cfg.skip_chn,
+                   aux_kernel_size=cfg.aux_kernel_size, aux_dilation_size=cfg.aux_dilation_size,
+                   dilation_depth=cfg.dilation_depth, dilation_repeat=cfg.dilation_repeat,
+                   kernel_size=cfg.kernel_size, upsampling_factor=cfg.upsampling_factor,
+                   seg=1 if soft else cfg.seg, lpc=0 if soft else cfg.lpc,
+                   n_quantize=cfg.n_quantize if soft else 0,
+                   wav_conv_flag=int(cfg.wav_conv_flag), audio_in_flag=int(cfg.audio_in_flag and soft),
+                   aux_conv2d_flag=int(cfg.aux_conv2d_flag and not soft))
+
+
+# name -> (restype, argtypes); must list every symbol include/swn_hip.h declares
+SIGNATURES = {
+    "swn_abi_version": (c_int, []),
+    "swn_strerror": (c_char_p, [c_int]),
+    "swn_device_count": (c_int, []),
+    "swn_receptive_field": (c_int, [POINTER(NetDesc)]),
+    "swn_num_tensors": (c_int, [POINTER(NetDesc)]),
+    "swn_packed_floats": (c_size_t, [POINTER(NetDesc)]),
+    "swn_pack_params": (c_int, [POINTER(NetDesc), POINTER(c_void_p), c_int, c_void_p, c_size_t]),
+    "swn_frontend_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
+    "swn_cond_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
+    "swn_frontend": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "swn_decode_state_floats": (c_size_t, [POINTER(NetDesc), c_int]),
+    "swn_decode": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+                           c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "swn_forward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
+    "swn_forward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
+                            c_void_p, c_void_p, c_void_p]),
+}
+
+
+def build(force: bool = False) -> str:
+    """compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("building libswn_hip.so failed:\n" + r.stdout + r.stderr)
+    return LIB_PATH
+
+
+def lib() -> ctypes.CDLL:
+    """load (building if absent) libswn_hip.so; raises RuntimeError when unavailable."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            build()
+        try:
+            l = ctypes.CDLL(LIB_PATH)
+        except OSError as e:
+            raise RuntimeError(f"shallow_wavenet_amd: cannot load {LIB_PATH}: {e}") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        if l.swn_abi_version() != 1:
+            raise RuntimeError("shallow_wavenet_amd: ABI version mismatch")
+        _lib = l
+        return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = lib().swn_strerror(rc).decode()
+        raise RuntimeError(f"swn_hip {what}: {msg} ({rc})")

@@ -1,0 +1,149 @@
+// Frame-rate front end on gfx950:
+//   scale_in (1x1)  ->  two-sided dilated k=3 conv stack  ->  hoisted in_x GEMM
+// Replaces  x = conv_aux(scale_in(aux))  and the per-sample-position  in_x[l](x)  1x1 convs of
+// cswnv_shift1.py:193,276,297 / dswnv.py:252,285,302.  The rank-1 ConvTranspose2d upsampler
+// (cswnv_shift1.py:37-65) is never materialised: consumers rebuild
+//   in_x(x)[o,t] = bx[l][o] + sum_s w_up[(t+s)%U] * cond[b][(t+s)/U][l][s][o].
+// All fp32 (decode parity needs fp32).  Frame-rate work is <1% of a decode.
+#include <hip/hip_runtime.h>
+#include "swn_geom.hpp"
+
+namespace {
+
+// out[b][co][f] = bias[co] + sum_ci sum_k W[co][ci][k] * in[b][ci][f + (k-(KS-1)/2)*dil]
+// block: 64 frames x 4 channel groups; thread computes CPT output channels of one frame.
+template <int CPT>
+__global__ __launch_bounds__(256) void conv1d_same_kernel(
+    const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int cin, int cout, int ks, int dil, int n_frames) {
+    const int f = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cg = threadIdx.x >> 6;                       // wave index -> channel group
+    const int co0 = (blockIdx.y * 4 + cg) * CPT;
+    const int b = blockIdx.z;
+    if (co0 >= cout) return;
+    const float* inb = in + (size_t)b * cin * n_frames;
+    float acc[CPT];
+#pragma unroll
+    for (int r = 0; r < CPT; ++r) acc[r] = (co0 + r < cout) ? bias[co0 + r] : 0.f;
+    const int half = (ks - 1) / 2;
+    for (int ci = 0; ci < cin; ++ci) {
+        for (int k = 0; k < ks; ++k) {
+            const int ff = f + (k - half) * dil;
+            const float x = (f < n_frames && ff >= 0 && ff < n_frames) ? inb[(size_t)ci * n_frames + ff] : 0.f;
+#pragma unroll
+            for (int r = 0; r < CPT; ++r) {
+                const int co = co0 + r;                   // wave-uniform -> scalar weight load
+                const float wv = (co < cout) ? w[((size_t)co * cin + ci) * ks + k] : 0.f;
+                acc[r] = fmaf(wv, x, acc[r]);
+            }
+        }
+    }
+    if (f < n_frames) {
+#pragma unroll
+        for (int r = 0; r < CPT; ++r)
+            if (co0 + r < cout) out[((size_t)b * cout + co0 + r) * n_frames + f] = acc[r];
+    }
+}
+
+// cond[b][f][n] = sum_c Wx[n][c] * C[b][c][f]     (M = frames of one utterance, N, Kd = A0)
+// 64x64 tile, BK = 16, 256 threads x (4x4) outputs, fp32 FMA chains in ascending c.
+__global__ __launch_bounds__(256) void cond_gemm_kernel(
+    const float* __restrict__ C, const float* __restrict__ Wx, float* __restrict__ cond,
+    int n_frames, int N, int A0, int A0p) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int b = blockIdx.z;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const int tm = (tid & 15) * 4, tn = (tid >> 4) * 4;
+    const float* Cb = C + (size_t)b * A0 * n_frames;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < A0; k0 += 16) {
+        // A tile: 16 k x 64 m, m contiguous in memory
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, mm = e & 63;
+            const int k = k0 + kk, m = m0 + mm;
+            As[kk][mm] = (k < A0 && m < n_frames) ? Cb[(size_t)k * n_frames + m] : 0.f;
+        }
+        // B tile: 64 n x 16 k, k contiguous in memory (rows padded to A0p, zero filled)
+        {
+            const int nn = tid >> 2, kq = (tid & 3) * 4;
+            const int n = n0 + nn, k = k0 + kq;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N && k < A0p) v = *reinterpret_cast<const float4*>(Wx + (size_t)n * A0p + k);
+            Bs[kq + 0][nn] = v.x; Bs[kq + 1][nn] = v.y; Bs[kq + 2][nn] = v.z; Bs[kq + 3][nn] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float4 a = *reinterpret_cast<const float4*>(&As[kk][tm]);
+            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][tn]);
+            const float av[4] = {a.x, a.y, a.z, a.w};
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + tm + i;
+        if (m >= n_frames) continue;
+        float* row = cond + ((size_t)b * n_frames + m) * N;
+        if (n0 + tn + 3 < N && (N & 3) == 0) {
+            *reinterpret_cast<float4*>(row + n0 + tn) = make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (n0 + tn + j < N) row[n0 + tn + j] = acc[i][j];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t swn_frontend_work_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    size_t tot = (size_t)g.n_aux;
+    for (int i = 0; i < g.auxl; ++i) tot += g.aux_cout[i];
+    return tot * (size_t)batch * n_frames;
+}
+
+extern "C" size_t swn_cond_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    return (size_t)batch * n_frames * g.N;
+}
+
+extern "C" int swn_frontend(const swn_net_desc* d, const float* packed, const float* aux,
+                            int batch, int n_frames, float* work, float* cond, void* stream_) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    if (rc < 0) return rc;
+    if (!packed || !aux || !work || !cond || batch < 1 || n_frames < 1 || batch > 65535) return SWN_E_BADARG;
+    SwnLayout y; swn_make_layout(&g, &y);
+    hipStream_t st = (hipStream_t)stream_;
+    const size_t bt = (size_t)batch * n_frames;
+    // scale_in
+    float* cur = work;
+    {
+        dim3 grid((n_frames + 63) / 64, (g.n_aux + 15) / 16, batch);
+        hipLaunchKernelGGL(conv1d_same_kernel<4>, grid, dim3(256), 0, st, aux, packed + y.scale_w,
+                           packed + y.scale_b, cur, g.n_aux, g.n_aux, 1, 1, n_frames);
+    }
+    const float* src = cur;
+    cur += bt * g.n_aux;
+    for (int i = 0; i < g.auxl; ++i) {
+        dim3 grid((n_frames + 63) / 64, (g.aux_cout[i] + 15) / 16, batch);
+        hipLaunchKernelGGL(conv1d_same_kernel<4>, grid, dim3(256), 0, st, src, packed + y.aux_w[i],
+                           packed + y.aux_b[i], cur, g.aux_cin[i], g.aux_cout[i], g.auxk, g.aux_dil[i], n_frames);
+        src = cur;
+        cur += bt * g.aux_cout[i];
+    }
+    {
+        dim3 grid((n_frames + 63) / 64, (g.N + 63) / 64, batch);
+        hipLaunchKernelGGL(cond_gemm_kernel, grid, dim3(256), 0, st, src, packed + y.wx, cond,
+                           n_frames, g.N, g.A0, g.A0p);
+    }
+    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+}

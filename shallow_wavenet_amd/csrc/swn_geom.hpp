@@ -1,0 +1,138 @@
+// Geometry and packed-parameter layout shared by the host packer and the gfx950 kernels.
+//
+// Everything is derived from the reference constructor arguments
+// (cswnv_shift1.py:130-189, dswnv.py:190-248): dilation K^(l mod dd), padding
+// K^(d+1)-K^d, rf = sum(padding)+K-1, in_x width A = 9*n_aux*seg, head width 2*seg+lpc | Q.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/swn_hip.h"
+
+#ifndef __HIPCC__
+#define __host__
+#define __device__
+#endif
+
+#define SWN_MAXL 16      // stack layers (dilation_depth * dilation_repeat)
+#define SWN_MAXAUX 4     // conditioning conv layers
+
+static inline __host__ __device__ int swn_round4(int x) { return (x + 3) & ~3; }
+
+struct SwnGeom {
+    int kind, n_aux, H, S, K, L, U, seg, lpc, Q, wav, audio_in;
+    int auxk, auxl;
+    int A0;        // conditioning channels after conv_aux = n_aux * auxk^auxl
+    int O1;        // out_1 width: S (laplace) | Q (softmax)
+    int NO;        // out_2 width: 2*seg+lpc | Q
+    int rf;
+    int Hp;        // H rounded up to 4 (row stride of every H-vector)
+    int Sp, O1p, A0p;
+    int N;         // conditioning row width per frame: L*seg*2H
+    int dil[SWN_MAXL];
+    int pad[SWN_MAXL];
+    int aux_cin[SWN_MAXAUX], aux_cout[SWN_MAXAUX], aux_dil[SWN_MAXAUX], aux_pad[SWN_MAXAUX];
+};
+
+// float offsets into the packed parameter buffer
+struct SwnLayout {
+    // ---- frame-rate section
+    size_t scale_w, scale_b;                 // [n_aux][n_aux], [n_aux]
+    size_t aux_w[SWN_MAXAUX], aux_b[SWN_MAXAUX];   // [cout][cin][k], [cout]
+    size_t wx;                               // [N][A0p]  row n=(l*seg+s)*2H+o : in_x[l].weight[o][c*seg+s]
+    size_t wxa;                              // softmax audio_in: [L][Q][2H]
+    // ---- sample-rate section
+    size_t wup, bup;                         // [U], [1]
+    size_t bx;                               // [L][2H] = in_x bias + b_up * sum_c,s W
+    size_t cb;                               // causal bias [H]
+    size_t cv, cc;                           // laplace: fused lift+causal taps [K][H] (value, constant)
+    size_t ct;                               // softmax: gather table [K][Q][H]
+    size_t wd, bd;                           // [L][2H][K][Hp], [L][2H]
+    size_t wsk, bsk;                         // [S][L*Hp], [S] (biases summed over layers)
+    size_t w1, b1;                           // [O1][Sp], [O1]
+    size_t w2, b2;                           // [NO][O1p], [NO]
+    size_t total;
+};
+
+static inline __host__ int swn_make_geom(const swn_net_desc* d, SwnGeom* g) {
+    if (!d || !g) return SWN_E_BADARG;
+    if (d->kind != SWN_KIND_LAPLACE && d->kind != SWN_KIND_SOFTMAX) return SWN_E_BADDESC;
+    int L = d->dilation_depth * d->dilation_repeat;
+    if (d->n_aux < 1 || d->hid_chn < 4 || d->skip_chn < 1 || d->kernel_size < 2 ||
+        d->dilation_depth < 1 || d->dilation_repeat < 1 || L > SWN_MAXL ||
+        d->upsampling_factor < 1 || d->aux_kernel_size < 1 || (d->aux_kernel_size & 1) == 0 ||
+        d->aux_dilation_size < 1 || d->aux_dilation_size > SWN_MAXAUX)
+        return SWN_E_BADDESC;
+    g->kind = d->kind; g->n_aux = d->n_aux; g->H = d->hid_chn; g->S = d->skip_chn;
+    g->K = d->kernel_size; g->L = L; g->U = d->upsampling_factor;
+    g->wav = d->wav_conv_flag ? 1 : 0;
+    if (d->kind == SWN_KIND_LAPLACE) {
+        if (d->seg < 1 || d->seg > 10 || d->lpc < 0 || d->lpc > 16) return SWN_E_BADDESC;
+        if (d->aux_conv2d_flag && d->seg > 1) return SWN_E_UNSUPPORTED;
+        g->seg = d->seg; g->lpc = d->lpc; g->Q = 0; g->audio_in = 0;
+        g->O1 = g->S; g->NO = 2 * g->seg + g->lpc;
+    } else {
+        if (d->n_quantize < 2 || d->n_quantize > 4096) return SWN_E_BADDESC;
+        g->seg = 1; g->lpc = 0; g->Q = d->n_quantize; g->audio_in = d->audio_in_flag ? 1 : 0;
+        g->O1 = g->Q; g->NO = g->Q;
+    }
+    g->auxk = d->aux_kernel_size; g->auxl = d->aux_dilation_size;
+    int c = d->n_aux, kp = 1;
+    for (int i = 0; i < g->auxl; ++i) {
+        g->aux_cin[i] = c; c *= g->auxk; g->aux_cout[i] = c;
+        g->aux_dil[i] = kp; g->aux_pad[i] = (kp * g->auxk - kp) / 2; kp *= g->auxk;
+    }
+    g->A0 = c;
+    long rf = g->K - 1;
+    for (int l = 0; l < L; ++l) {
+        long dl = 1;
+        for (int e = 0; e < (l % d->dilation_depth); ++e) dl *= g->K;
+        if (dl * g->K > (1 << 24)) return SWN_E_BADDESC;
+        g->dil[l] = (int)dl; g->pad[l] = (int)(dl * g->K - dl);
+        rf += g->pad[l];
+    }
+    g->rf = (int)rf;
+    g->Hp = swn_round4(g->H); g->Sp = swn_round4(g->S); g->O1p = swn_round4(g->O1);
+    g->A0p = swn_round4(g->A0);
+    g->N = L * g->seg * 2 * g->H;
+    return SWN_OK;
+}
+
+static inline __host__ size_t swn_al(size_t x) { return (x + 63) & ~(size_t)63; }   // 256-B sections
+
+static inline __host__ void swn_make_layout(const SwnGeom* g, SwnLayout* y) {
+    size_t o = 0;
+    y->scale_w = o; o = swn_al(o + (size_t)g->n_aux * g->n_aux);
+    y->scale_b = o; o = swn_al(o + g->n_aux);
+    for (int i = 0; i < SWN_MAXAUX; ++i) { y->aux_w[i] = 0; y->aux_b[i] = 0; }
+    for (int i = 0; i < g->auxl; ++i) {
+        y->aux_w[i] = o; o = swn_al(o + (size_t)g->aux_cout[i] * g->aux_cin[i] * g->auxk);
+        y->aux_b[i] = o; o = swn_al(o + g->aux_cout[i]);
+    }
+    y->wx = o; o = swn_al(o + (size_t)g->N * g->A0p);
+    y->wxa = o; if (g->audio_in) o = swn_al(o + (size_t)g->L * g->Q * 2 * g->H);
+    y->wup = o; o = swn_al(o + g->U);
+    y->bup = o; o = swn_al(o + 1);
+    y->bx = o; o = swn_al(o + (size_t)g->L * 2 * g->H);
+    y->cb = o; o = swn_al(o + g->H);
+    y->cv = o; y->cc = o; y->ct = o;
+    if (g->kind == SWN_KIND_LAPLACE) {
+        y->cv = o; o = swn_al(o + (size_t)g->K * g->H);
+        y->cc = o; o = swn_al(o + (size_t)g->K * g->H);
+    } else {
+        y->ct = o; o = swn_al(o + (size_t)g->K * g->Q * g->H);
+    }
+    y->wd = o; o = swn_al(o + (size_t)g->L * 2 * g->H * g->K * g->Hp);
+    y->bd = o; o = swn_al(o + (size_t)g->L * 2 * g->H);
+    y->wsk = o; o = swn_al(o + (size_t)g->S * g->L * g->Hp);
+    y->bsk = o; o = swn_al(o + g->S);
+    y->w1 = o; o = swn_al(o + (size_t)g->O1 * g->Sp);
+    y->b1 = o; o = swn_al(o + g->O1);
+    y->w2 = o; o = swn_al(o + (size_t)g->NO * g->O1p);
+    y->b2 = o; o = swn_al(o + g->NO);
+    y->total = o;
+}
+
+// number of state_dict tensors in reference order (shallow_wavenet_amd/config.py param_shapes)
+static inline __host__ int swn_tensor_count(const SwnGeom* g) {
+    return 2 + 2 * g->auxl + 2 + (g->wav ? 2 : 0) + 2 + 6 * g->L + 4;
+}

@@ -1,0 +1,155 @@
+// Host-side parameter packing: reference state_dict tensors -> one flat fp32 buffer.
+// (replaces the per-process torch.load + load_state_dict of
+//  decode_cswnv_laplace-shift1.py:223-224 as the thing that reaches the GPU; the packed
+//  buffer is uploaded once and broadcast over RCCL.)
+#include <math.h>
+#include <string.h>
+#include <vector>
+#include "swn_geom.hpp"
+
+extern "C" int swn_abi_version(void) { return SWN_ABI_VERSION; }
+
+extern "C" const char* swn_strerror(int code) {
+    switch (code) {
+        case SWN_OK: return "ok";
+        case SWN_E_BADDESC: return "network descriptor outside supported range";
+        case SWN_E_BADARG: return "bad argument (null pointer or size mismatch)";
+        case SWN_E_LAUNCH: return "HIP kernel launch failed";
+        case SWN_E_UNSUPPORTED: return "configuration not supported by this build";
+        case SWN_E_NODEVICE: return "no HIP device";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int swn_receptive_field(const swn_net_desc* d) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    return rc < 0 ? rc : g.rf;
+}
+
+extern "C" int swn_num_tensors(const swn_net_desc* d) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    return rc < 0 ? rc : swn_tensor_count(&g);
+}
+
+extern "C" size_t swn_packed_floats(const swn_net_desc* d) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0) return 0;
+    SwnLayout y; swn_make_layout(&g, &y);
+    return y.total;
+}
+
+extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int n_tensors,
+                               float* out, size_t out_floats) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    if (rc < 0) return rc;
+    SwnLayout y; swn_make_layout(&g, &y);
+    if (!t || !out || n_tensors != swn_tensor_count(&g) || out_floats < y.total) return SWN_E_BADARG;
+    for (int i = 0; i < n_tensors; ++i) if (!t[i]) return SWN_E_BADARG;
+    memset(out, 0, y.total * sizeof(float));
+    const int H = g.H, S = g.S, K = g.K, L = g.L, seg = g.seg, Q = g.Q, H2 = 2 * g.H;
+    int ti = 0;
+    // ---- frame-rate section: scale_in, conv_aux (copied as they are)
+    memcpy(out + y.scale_w, t[ti++], sizeof(float) * g.n_aux * g.n_aux);
+    memcpy(out + y.scale_b, t[ti++], sizeof(float) * g.n_aux);
+    for (int i = 0; i < g.auxl; ++i) {
+        memcpy(out + y.aux_w[i], t[ti++], sizeof(float) * g.aux_cout[i] * g.aux_cin[i] * g.auxk);
+        memcpy(out + y.aux_b[i], t[ti++], sizeof(float) * g.aux_cout[i]);
+    }
+    // ---- rank-1 upsampler
+    const float* wup = t[ti++];
+    const float* bup = t[ti++];
+    memcpy(out + y.wup, wup, sizeof(float) * g.U);
+    out[y.bup] = bup[0];
+    // ---- sample lift (optional) and causal input layer
+    const float* wav_w = nullptr; const float* wav_b = nullptr;
+    if (g.wav) { wav_w = t[ti++]; wav_b = t[ti++]; }
+    const float* cw = t[ti++];          // (H, Cin, K)
+    const float* cbias = t[ti++];
+    memcpy(out + y.cb, cbias, sizeof(float) * H);
+    const int cin = g.wav ? H : (g.kind == SWN_KIND_LAPLACE ? 1 : Q);
+    if (g.kind == SWN_KIND_LAPLACE) {
+        for (int k = 0; k < K; ++k)
+            for (int o = 0; o < H; ++o) {
+                if (g.wav) {
+                    double sv = 0, sc = 0;
+                    for (int i = 0; i < H; ++i) {
+                        double w = cw[((size_t)o * cin + i) * K + k];
+                        sv += w * wav_w[i]; sc += w * wav_b[i];
+                    }
+                    out[y.cv + (size_t)k * H + o] = (float)sv;
+                    out[y.cc + (size_t)k * H + o] = (float)sc;
+                } else {
+                    out[y.cv + (size_t)k * H + o] = cw[(size_t)o * K + k];
+                }
+            }
+    } else {
+        for (int k = 0; k < K; ++k)
+            for (int q = 0; q < Q; ++q)
+                for (int o = 0; o < H; ++o) {
+                    float v;
+                    if (g.wav) {
+                        double s = 0;
+                        for (int i = 0; i < H; ++i)
+                            s += (double)cw[((size_t)o * cin + i) * K + k] * ((double)wav_w[(size_t)i * Q + q] + wav_b[i]);
+                        v = (float)s;
+                    } else {
+                        v = cw[((size_t)o * cin + q) * K + k];
+                    }
+                    out[y.ct + ((size_t)k * Q + q) * H + o] = v;
+                }
+    }
+    // ---- in_x: stacked rows for the frame-rate GEMM, bias folded with the upsampler bias
+    const int A = g.A0 * seg + (g.audio_in ? Q : 0);
+    for (int l = 0; l < L; ++l) {
+        const float* w = t[ti++];       // (2H, A, 1)
+        const float* b = t[ti++];
+        for (int o = 0; o < H2; ++o) {
+            double ws = 0;
+            for (int c = 0; c < g.A0; ++c)
+                for (int s = 0; s < seg; ++s) {
+                    float v = w[(size_t)o * A + c * seg + s];
+                    ws += v;
+                    out[y.wx + ((size_t)(l * seg + s) * H2 + o) * g.A0p + c] = v;
+                }
+            out[y.bx + (size_t)l * H2 + o] = (float)((double)b[o] + (double)bup[0] * ws);
+            if (g.audio_in)
+                for (int q = 0; q < Q; ++q)
+                    out[y.wxa + ((size_t)l * Q + q) * H2 + o] = w[(size_t)o * A + g.A0 + q];
+        }
+    }
+    // ---- dilated convs: tap-major rows [o][k][i]
+    for (int l = 0; l < L; ++l) {
+        const float* w = t[ti++];       // (2H, H, K)
+        const float* b = t[ti++];
+        for (int o = 0; o < H2; ++o)
+            for (int i = 0; i < H; ++i)
+                for (int k = 0; k < K; ++k)
+                    out[y.wd + (((size_t)l * H2 + o) * K + k) * g.Hp + i] = w[((size_t)o * H + i) * K + k];
+        memcpy(out + y.bd + (size_t)l * H2, b, sizeof(float) * H2);
+    }
+    // ---- skip 1x1s concatenated along the input axis, biases summed
+    std::vector<double> bs(S, 0.0);
+    for (int l = 0; l < L; ++l) {
+        const float* w = t[ti++];       // (S, H, 1)
+        const float* b = t[ti++];
+        for (int c = 0; c < S; ++c) {
+            for (int i = 0; i < H; ++i)
+                out[y.wsk + (size_t)c * L * g.Hp + (size_t)l * g.Hp + i] = w[(size_t)c * H + i];
+            bs[c] += b[c];
+        }
+    }
+    for (int c = 0; c < S; ++c) out[y.bsk + c] = (float)bs[c];
+    // ---- output 1x1s
+    {
+        const float* w = t[ti++]; const float* b = t[ti++];      // (O1, S, 1)
+        for (int o = 0; o < g.O1; ++o)
+            memcpy(out + y.w1 + (size_t)o * g.Sp, w + (size_t)o * S, sizeof(float) * S);
+        memcpy(out + y.b1, b, sizeof(float) * g.O1);
+    }
+    {
+        const float* w = t[ti++]; const float* b = t[ti++];      // (NO, O1, 1)
+        for (int o = 0; o < g.NO; ++o)
+            memcpy(out + y.w2 + (size_t)o * g.O1p, w + (size_t)o * g.O1, sizeof(float) * g.O1);
+        memcpy(out + y.b2, b, sizeof(float) * g.NO);
+    }
+    return ti == n_tensors ? SWN_OK : SWN_E_BADARG;
+}

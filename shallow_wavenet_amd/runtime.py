@@ -1,0 +1,143 @@
+"""Host runtime over the C ABI: packed parameters in HBM, scratch buffers, launches.
+
+torch is used for device memory, streams and (in `dist.py`) RCCL only; every arithmetic
+step of the hot path is a HIP kernel behind `include/swn_hip.h`.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from .config import NetConfig
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream_ptr(device) -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def pack_state_dict(cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Tensor"]) -> torch.Tensor:
+    """reference state_dict (any device) -> flat fp32 host tensor in kernel layout
+    (swn_pack_params; layout documented in csrc/swn_geom.hpp)."""
+    L = _lib.lib()
+    desc = _lib.desc_from_cfg(cfg)
+    shapes = cfg.param_shapes()
+    n = L.swn_num_tensors(ctypes.byref(desc))
+    if n < 0:
+        _lib.check(n, "descriptor")
+    if n != len(shapes):
+        raise RuntimeError("tensor count mismatch between host config and library")
+    host = []
+    for name, shp in shapes:
+        if name not in state_dict:
+            raise KeyError(f"state_dict is missing {name}")
+        v = state_dict[name]
+        v = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+        if tuple(v.shape) != tuple(shp):
+            raise RuntimeError(f"{name}: shape {tuple(v.shape)} != reference shape {tuple(shp)}")
+        host.append(np.ascontiguousarray(v, dtype=np.float32))
+    ptrs = (ctypes.c_void_p * n)(*[h.ctypes.data for h in host])
+    total = L.swn_packed_floats(ctypes.byref(desc))
+    packed = torch.zeros(total, dtype=torch.float32)
+    _lib.check(L.swn_pack_params(ctypes.byref(desc), ptrs, n, ctypes.c_void_p(packed.data_ptr()), total),
+               "pack_params")
+    return packed
+
+
+class HipNet:
+    """One network's packed parameters resident in HBM plus the launch helpers."""
+
+    def __init__(self, cfg: NetConfig, packed: torch.Tensor, device):
+        if not torch.cuda.is_available():
+            raise RuntimeError("shallow_wavenet_amd needs a HIP device (no CPU fallback)")
+        self.cfg = cfg
+        self.desc = _lib.desc_from_cfg(cfg)
+        self.device = torch.device(device)
+        self.lib = _lib.lib()
+        self.packed = packed.to(self.device, non_blocking=False).contiguous()
+
+    @classmethod
+    def from_state_dict(cls, cfg: NetConfig, state_dict, device) -> "HipNet":
+        return cls(cfg, pack_state_dict(cfg, state_dict), device)
+
+    # ------------------------------------------------------------------ front end
+    def frontend(self, aux: torch.Tensor) -> torch.Tensor:
+        """aux (B, n_aux, Tf) fp32 on device -> cond (B, Tf, L*seg*2H)."""
+        cfg, L = self.cfg, self.lib
+        aux = aux.to(self.device, torch.float32).contiguous()
+        B, na, Tf = aux.shape
+        if na != cfg.n_aux:
+            raise RuntimeError(f"aux has {na} channels, model expects {cfg.n_aux}")
+        d = ctypes.byref(self.desc)
+        work = torch.empty(L.swn_frontend_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        cond = torch.empty(L.swn_cond_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_frontend(d, _ptr(self.packed), _ptr(aux), B, Tf, _ptr(work), _ptr(cond),
+                                      _stream_ptr(self.device)), "frontend")
+        return cond.view(B, Tf, -1)
+
+    # ------------------------------------------------------------------ decode
+    def decode(self, aux: torch.Tensor, n_steps: int, noise: torch.Tensor,
+               forced: Optional[torch.Tensor] = None, want_heads: bool = False, variant: int = 0,
+               cond: Optional[torch.Tensor] = None):
+        """run prologue + n_steps generation steps for every utterance of the batch.
+
+        noise: laplace (B, n_steps, seg) | softmax (B, n_steps, Q), fp32, utterance-major.
+        returns (out, heads): out laplace (B, n_steps*seg) fp32 | softmax (B, n_steps) int32.
+        """
+        cfg, L = self.cfg, self.lib
+        soft = cfg.kind == "softmax"
+        if cond is None:
+            cond = self.frontend(aux)
+        B, Tf = cond.shape[0], cond.shape[1]
+        seg = 1 if soft else cfg.seg
+        width = cfg.n_quantize if soft else seg
+        noise = noise.to(self.device, torch.float32).contiguous()
+        if tuple(noise.shape) != (B, n_steps, width):
+            raise RuntimeError(f"noise shape {tuple(noise.shape)} != {(B, n_steps, width)}")
+        if forced is not None:
+            forced = forced.to(self.device, torch.int32 if soft else torch.float32).contiguous()
+            if forced.numel() != B * n_steps * seg:
+                raise RuntimeError("forced history has the wrong size")
+        d = ctypes.byref(self.desc)
+        state = torch.empty(L.swn_decode_state_floats(d, B), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, n_steps * seg), dtype=torch.int32 if soft else torch.float32, device=self.device)
+        heads = torch.empty((B, n_steps, cfg.n_out), dtype=torch.float32, device=self.device) if want_heads else None
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_decode(d, _ptr(self.packed), _ptr(cond), B, Tf, n_steps, _ptr(noise),
+                                    _ptr(forced), _ptr(state), _ptr(out), _ptr(heads), variant,
+                                    _stream_ptr(self.device)), "decode")
+        return out, heads
+
+    # ------------------------------------------------------------------ teacher-forced stack
+    def forward(self, aux: torch.Tensor, audio: torch.Tensor, want_hidden: bool = False,
+                cond: Optional[torch.Tensor] = None):
+        """raw out_2 outputs (B, n_out, Tp) of the teacher-forced stack.
+        audio: laplace (B, 1, T-seg) fp32 | softmax (B, T-1) integer indices."""
+        cfg, L = self.cfg, self.lib
+        soft = cfg.kind == "softmax"
+        if cond is None:
+            cond = self.frontend(aux)
+        B, Tf = cond.shape[0], cond.shape[1]
+        T = Tf * cfg.U
+        seg = 1 if soft else cfg.seg
+        Tp = T - 1 if soft else T - 2 * seg + 1
+        audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
+        need = B * (T - seg)
+        if audio.numel() != need:
+            raise RuntimeError(f"audio has {audio.numel()} elements, expected {need}")
+        d = ctypes.byref(self.desc)
+        work = torch.empty(L.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
+        hs = torch.empty((cfg.L + 1, B, cfg.H, Tp), dtype=torch.float32, device=self.device) if want_hidden else None
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
+                                     _ptr(out), _ptr(hs), _stream_ptr(self.device)), "forward")
+        return out, hs
