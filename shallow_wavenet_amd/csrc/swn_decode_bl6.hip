@@ -1,8 +1,519 @@
-// placeholder: the register/LDS-resident BL6-class decode kernel is added next.
+// BL6-class autoregressive decode on gfx950 (BASELINE-literal shape: 1x6 dilated stack, H=64,
+// K=2, dilations 1..32, rf=64; Laplace S=128 with seg/lpc variants, softmax S=Q=256).
+//
+// One persistent 512-thread workgroup (8 waves, 2 per SIMD) per utterance.  What makes it
+// different from the generic kernel (swn_decode.hip):
+//   * the six dilated-conv weight matrices (6 x 128 x 128 fp32 = 384 KB) live in VGPRs for the
+//     whole utterance: thread (o,p) owns gate row o and candidate row o+64 over 16 of the
+//     128 inputs, 192 registers; rows are reduced over 8 adjacent lanes with DPP adds;
+//   * the per-dilation history rings (cswnv_shift1.py:324-334 output_buffer) are LDS rings
+//     with power-of-two lengths: 32-36 KB; a tap is one broadcast ds_read_b128 per 16 bytes;
+//   * the gate  z=sigmoid, tanh, highway  epilogue is fused behind the reduction (no second
+//     pass, one s_barrier per layer); with seg>1 lane p finishes position p;
+//   * out_skip is accumulated layer by layer in the shadow of the next layer's phase, so only
+//     one 128x64 slice sits on the critical path; out_1/out_skip stream from L2 in a
+//     lane-tiled layout (1 KiB contiguous per wave instruction);
+//   * conditioning: the current and next frame of the hoisted in_x product sit in LDS, the
+//     rank-1 upsampler is one fma per gate input (cswnv_shift1.py:37-65,276).
+// 9 s_barriers per generated step (10 for softmax).
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
 
-extern "C" int swn_decode_bl6_try(const swn_net_desc*, const float*, const float*, int, int, int,
-                                  const float*, const void*, void*, float*, void*) {
+namespace {
+
+constexpr int NT = 512;
+constexpr int H = 64;
+constexpr int L = 6;
+constexpr int RF = 64;
+
+struct B6Args {
+    const float* P;
+    SwnLayout y;
+    const float* cond;
+    const float* noise;
+    const void* forced;
+    void* out;
+    float* heads;
+    int B, Tf, n_steps, U, N;
+};
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int pow2ceil(int x) { int r = 1; while (r < x) r <<= 1; return r; }
+constexpr int r4(int x) { return (x + 3) & ~3; }
+
+template <int S_, int SEG_, int LPC_, int KIND_, int Q_>
+struct Tr {
+    static constexpr int S = S_, SEG = SEG_, LPC = LPC_, KIND = KIND_, Q = Q_;
+    static constexpr int O1 = KIND_ == SWN_KIND_SOFTMAX ? Q_ : S_;
+    static constexpr int NO = KIND_ == SWN_KIND_SOFTMAX ? Q_ : 2 * SEG_ + LPC_;
+    static constexpr int WN = cmax(1, LPC_) + SEG_;
+    static constexpr int ring_len(int l) { return pow2ceil((1 << l) + SEG_); }
+    static constexpr int ring_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += ring_len(i) * H; return o; }
+    static constexpr int PF = L * SEG_ * 2 * H;          // floats of one conditioning frame
+    static constexpr int NREG = 5;                        // layers whose weights stay in VGPRs; the rest sit in LDS
+    // LDS carve (float offsets)
+    static constexpr int o_ring = 0;
+    static constexpr int o_hcat = o_ring + ring_off(L);
+    static constexpr int o_gp = o_hcat + L * H;
+    static constexpr int o_bx = o_gp + 2 * PF;
+    static constexpr int o_bd = o_bx + L * 2 * H;
+    static constexpr int o_wup = o_bd + L * 2 * H;
+    static constexpr int o_skip = o_wup + 256;
+    static constexpr int o_o1 = o_skip + S_;
+    static constexpr int o_o2 = o_o1 + O1;
+    static constexpr int o_hist = o_o2 + r4(NO);
+    static constexpr int o_cz = o_hist + r4(WN);          // cb[64], cv[2][64], cc[2][64]
+    static constexpr int o_w2 = o_cz + 5 * H;             // laplace: out_2 rows [NO][S] (+b2)
+    static constexpr int o_wl = o_w2 + (KIND_ == SWN_KIND_LAPLACE ? NO * S_ + r4(NO) : 0);   // [L-NREG][8][512][4]
+    static constexpr int o_end = o_wl + (L - NREG) * 8 * NT * 4;
+    static constexpr size_t lds_bytes = (size_t)o_end * sizeof(float);
+};
+
+// Streamed weights go through a buffer resource: one 32-bit per-thread offset plus scalar /
+// immediate offsets per load, instead of a 64-bit VGPR address per load (which spilled).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t r, unsigned voff_bytes, unsigned soff_bytes) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff_bytes, soff_bytes, 0));
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float sum4(float v) {      // all 4 lanes of a quad get the quad sum
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    return v;
+}
+__device__ __forceinline__ float sum8(float v) {      // all 8 lanes of an aligned octet get the sum
+    v = sum4(v);
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float ssign(float x) { return x / (1.f + fabsf(x)); }
+
+template <int NP>
+__device__ __forceinline__ float pick(const float (&a)[NP], int p) {
+    float v = a[0];
+#pragma unroll
+    for (int j = 1; j < NP; ++j) v = (p == j) ? a[j] : v;
+    return v;
+}
+
+// One DCRNN layer for NP consecutive positions q0..q0+NP-1 (cswnv_shift1.py:281-285).
+template <class T, int LAYER, int NP>
+__device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float (&w)[2][16], int q0,
+                                            const float (&wj)[T::SEG], const int (&pb)[T::SEG]) {
+    constexpr int dil = 1 << LAYER;
+    constexpr int R = T::ring_len(LAYER);
+    const int tid = threadIdx.x, o = tid >> 3, p = tid & 7;
+    const float* ring = lds + T::o_ring + T::ring_off(LAYER);
+    float az[NP], ac[NP];
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { az[j] = 0.f; ac[j] = 0.f; }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        // inputs 32m+4p..+3 of [tap0 = position q-dil | tap1 = position q]
+        float4 w0, w1;
+        if (LAYER < T::NREG) {
+            w0 = make_float4(w[0][4 * m], w[0][4 * m + 1], w[0][4 * m + 2], w[0][4 * m + 3]);
+            w1 = make_float4(w[1][4 * m], w[1][4 * m + 1], w[1][4 * m + 2], w[1][4 * m + 3]);
+        } else {
+            constexpr int wl = LAYER < T::NREG ? 0 : LAYER - T::NREG;
+            w0 = *reinterpret_cast<const float4*>(lds + T::o_wl + ((wl * 8 + m) * NT + tid) * 4);
+            w1 = *reinterpret_cast<const float4*>(lds + T::o_wl + ((wl * 8 + 4 + m) * NT + tid) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NP; ++j) {
+            const int pos = q0 + j - (m < 2 ? dil : 0);
+            const float4 x = *reinterpret_cast<const float4*>(ring + (pos & (R - 1)) * H + 32 * (m & 1) + 4 * p);
+            az[j] = fmaf(w0.x, x.x, az[j]); ac[j] = fmaf(w1.x, x.x, ac[j]);
+            az[j] = fmaf(w0.y, x.y, az[j]); ac[j] = fmaf(w1.y, x.y, ac[j]);
+            az[j] = fmaf(w0.z, x.z, az[j]); ac[j] = fmaf(w1.z, x.z, ac[j]);
+            az[j] = fmaf(w0.w, x.w, az[j]); ac[j] = fmaf(w1.w, x.w, ac[j]);
+        }
+        // keep the scheduler from hoisting every tap read of the phase at once (80 VGPRs at seg=5)
+        if (NP > 2) __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int j = 0; j < NP; ++j) { az[j] = sum8(az[j]); ac[j] = sum8(ac[j]); }
+    if (p < NP) {                                   // lane p finishes position q0+p
+        const int q = q0 + p;
+        const float sz = pick<NP>(az, p) + lds[T::o_bd + LAYER * 2 * H + o];
+        const float sc = pick<NP>(ac, p) + lds[T::o_bd + LAYER * 2 * H + H + o];
+        float gz = lds[T::o_bx + LAYER * 2 * H + o];
+        float gc = lds[T::o_bx + LAYER * 2 * H + H + o];
+#pragma unroll
+        for (int s = 0; s < T::SEG; ++s) {
+            const float* pr = lds + T::o_gp + pb[s] + (LAYER * T::SEG + s) * 2 * H;
+            gz = fmaf(wj[s], pr[o], gz);
+            gc = fmaf(wj[s], pr[H + o], gc);
+        }
+        const float z = sigm(gz * sz);
+        const float c = tanhf(gc * sc);
+        const float hp = ring[(q & (R - 1)) * H + o];
+        const float hn = (1.f - z) * c + z * hp;
+        if (LAYER + 1 < L) {
+            constexpr int R2 = T::ring_len(LAYER + 1 < L ? LAYER + 1 : LAYER);
+            lds[T::o_ring + T::ring_off(LAYER + 1 < L ? LAYER + 1 : LAYER) + (q & (R2 - 1)) * H + o] = hn;
+        }
+        if (p == NP - 1) lds[T::o_hcat + LAYER * H + o] = hn;
+    }
+}
+
+// out_skip slice of one layer, 4 lanes per row, weights streamed from the lane-tiled copy.
+template <class T, int LAYER>
+__device__ __forceinline__ void skip_slice(const float* __restrict__ lds, __amdgpu_buffer_rsrc_t wsk2,
+                                           float (&sacc)[T::S / 128]) {
+    constexpr int layer = LAYER;
+    const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
+#pragma unroll
+    for (int ps = 0; ps < T::S / 128; ++ps) {
+        const int row = hr + 128 * ps;
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const float4 w = buf_ld4(wsk2, (unsigned)(row * 4 + hp) * 16u, (unsigned)((layer * 4 + mm) * T::S) * 64u);
+            const float4 x = *reinterpret_cast<const float4*>(lds + T::o_hcat + layer * H + 16 * mm + 4 * hp);
+            sacc[ps] = fmaf(w.x, x.x, sacc[ps]); sacc[ps] = fmaf(w.y, x.y, sacc[ps]);
+            sacc[ps] = fmaf(w.z, x.z, sacc[ps]); sacc[ps] = fmaf(w.w, x.w, sacc[ps]);
+        }
+    }
+}
+
+// rows x NI mat-vec, 4 lanes per row, lane-tiled weights [NI/16][rows][4][4] streamed from L2.
+template <int ROWS, int NI>
+__device__ __forceinline__ void tiled_matvec(__amdgpu_buffer_rsrc_t wt, const float* __restrict__ bias,
+                                             const float* x, float* y, bool relu) {
+    const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
+#pragma unroll
+    for (int ps = 0; ps < ROWS / 128; ++ps) {
+        const int row = hr + 128 * ps;
+        float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+        for (int mm = 0; mm < NI / 16; mm += 2) {
+            const float4 w0 = buf_ld4(wt, (unsigned)(row * 4 + hp) * 16u, (unsigned)(mm * ROWS) * 64u);
+            const float4 w1 = buf_ld4(wt, (unsigned)(row * 4 + hp) * 16u, (unsigned)((mm + 1) * ROWS) * 64u);
+            const float4 x0 = *reinterpret_cast<const float4*>(x + 16 * mm + 4 * hp);
+            const float4 x1 = *reinterpret_cast<const float4*>(x + 16 * (mm + 1) + 4 * hp);
+            a0 = fmaf(w0.x, x0.x, a0); a0 = fmaf(w0.y, x0.y, a0); a0 = fmaf(w0.z, x0.z, a0); a0 = fmaf(w0.w, x0.w, a0);
+            a1 = fmaf(w1.x, x1.x, a1); a1 = fmaf(w1.y, x1.y, a1); a1 = fmaf(w1.z, x1.z, a1); a1 = fmaf(w1.w, x1.w, a1);
+            if ((mm & 7) == 6 && mm + 2 < NI / 16) __builtin_amdgcn_sched_barrier(0);   // <= 8 loads in flight
+        }
+        float v = sum4(a0 + a1);
+        if (hp == 0) {
+            v += bias[row];
+            y[row] = relu ? fmaxf(v, 0.f) : v;
+        }
+    }
+}
+
+template <class T>
+__global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int SEG = T::SEG, S = T::S, KIND = T::KIND;
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const float* __restrict__ P = a.P;
+    const int U = a.U;
+
+    // ---- one-time loads: LDS constants, register-resident dilated-conv weights
+    for (int e = tid; e < T::o_end; e += NT) lds[e] = 0.f;
+    __syncthreads();
+    for (int e = tid; e < L * 2 * H; e += NT) { lds[T::o_bx + e] = P[a.y.bx + e]; lds[T::o_bd + e] = P[a.y.bd + e]; }
+    for (int e = tid; e < U; e += NT) lds[T::o_wup + e] = P[a.y.wup + e];
+    for (int e = tid; e < H; e += NT) lds[T::o_cz + e] = P[a.y.cb + e];
+    if (KIND == SWN_KIND_LAPLACE) {
+        for (int e = tid; e < 2 * H; e += NT) { lds[T::o_cz + H + e] = P[a.y.cv + e]; lds[T::o_cz + 3 * H + e] = P[a.y.cc + e]; }
+        for (int e = tid; e < T::NO * S; e += NT) lds[T::o_w2 + e] = P[a.y.w2 + (size_t)(e / S) * r4(S) + (e % S)];
+        for (int e = tid; e < T::NO; e += NT) lds[T::o_w2 + T::NO * S + e] = P[a.y.b2 + e];
+    }
+    int* ihist = reinterpret_cast<int*>(lds + T::o_hist);
+    if (KIND == SWN_KIND_SOFTMAX)
+        for (int e = tid; e < T::WN; e += NT) ihist[e] = T::Q / 2;
+    // conditioning frames are copied 16 B per lane through a buffer resource (32-bit offsets)
+    const __amdgpu_buffer_rsrc_t condr =
+        make_rsrc(a.cond + (size_t)b * a.Tf * a.N, (unsigned)((size_t)a.Tf * a.N * sizeof(float)));
+    auto load_frame = [&](int fr) {
+        float* dst = lds + T::o_gp + (fr & 1) * T::PF;
+#pragma unroll
+        for (int it = 0; it < (T::PF / 4 + NT - 1) / NT; ++it) {
+            const int e4 = it * NT + tid;
+            if (e4 < T::PF / 4)
+                *reinterpret_cast<float4*>(dst + 4 * e4) =
+                    buf_ld4(condr, (unsigned)tid * 16u, (unsigned)(fr * a.N * 4 + it * NT * 16));
+        }
+    };
+    for (int fr = 0; fr < 2 && fr < a.Tf; ++fr) load_frame(fr);
+    float wreg[L][2][16];
+#pragma unroll
+    for (int l = 0; l < L; ++l) {
+        const float4* src = reinterpret_cast<const float4*>(P + a.y.wd2 + ((size_t)l * NT + tid) * 32);
+#pragma unroll
+        for (int v = 0; v < 8; ++v) {
+            const float4 t = src[v];
+            if (l < T::NREG) {
+                wreg[l][v >> 2][4 * (v & 3) + 0] = t.x; wreg[l][v >> 2][4 * (v & 3) + 1] = t.y;
+                wreg[l][v >> 2][4 * (v & 3) + 2] = t.z; wreg[l][v >> 2][4 * (v & 3) + 3] = t.w;
+            } else {
+                *reinterpret_cast<float4*>(lds + T::o_wl + (((l - T::NREG) * 8 + v) * NT + tid) * 4) = t;
+                wreg[l][v >> 2][4 * (v & 3) + 0] = 0.f; wreg[l][v >> 2][4 * (v & 3) + 1] = 0.f;
+                wreg[l][v >> 2][4 * (v & 3) + 2] = 0.f; wreg[l][v >> 2][4 * (v & 3) + 3] = 0.f;
+            }
+        }
+    }
+    __syncthreads();
+
+    int fb = 0, tb = 0;                       // base conditioning frame resident in buffer fb&1
+    const int p = tid & 7;
+    const int n_pro = RF - SEG + 1;
+
+    // conditioning taps of the position this lane finishes: upsampler weight and frame buffer offset
+    auto cond_taps = [&](int q0, float (&wj)[SEG], int (&pb)[SEG]) {
+        const int t0 = q0 - RF;
+        const int tlo = t0 < 0 ? 0 : t0;
+        if (tlo >= tb + U) {                  // step crossed into the next frame: refill the free buffer
+            fb += 1; tb += U;
+            if (fb + 1 < a.Tf) load_frame(fb + 1);
+        }
+#pragma unroll
+        for (int s = 0; s < SEG; ++s) {
+            int tt = t0 + p + s; tt = tt < 0 ? 0 : tt;
+            int rel = tt - tb;
+            int fsel = fb;
+            if (rel >= U) { rel -= U; fsel = fb + 1; }
+            rel = rel < U ? rel : U - 1;
+            wj[s] = lds[T::o_wup + rel];
+            pb[s] = (fsel & 1) * T::PF;
+        }
+    };
+
+    // input layer h0 = softsign(causal(lift(S)))  (wave 0; fused wav_conv+causal taps)
+    auto input_phase = [&](int q0, int np, bool gen) {
+        if (tid < H) {
+            const int o = tid;
+            constexpr int R0 = T::ring_len(0);
+            for (int j = 0; j < np; ++j) {
+                const int q = q0 + j;
+                const int qe = q0 + np - 1;
+                float acc = lds[T::o_cz + o];
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    const int r = q - (1 - k);
+                    if (KIND == SWN_KIND_LAPLACE) {
+                        if (r >= -(SEG - 1)) {
+                            const float sv = gen ? lds[T::o_hist + r - qe + T::WN - 1] : 0.f;
+                            acc += fmaf(lds[T::o_cz + H + k * H + o], sv, lds[T::o_cz + 3 * H + k * H + o]);
+                        }
+                    } else {
+                        if (r >= 0) {
+                            const int idx = gen ? ihist[r - qe + T::WN - 1] : T::Q / 2;
+                            acc += P[a.y.ct + ((size_t)k * T::Q + idx) * H + o];
+                        }
+                    }
+                }
+                lds[T::o_ring + (q & (R0 - 1)) * H + o] = ssign(acc);
+            }
+        }
+    };
+
+    // ---- prologue: seed positions 0..rf-seg, one position per pass (cswnv_shift1.py:321-334)
+    for (int q = 0; q < n_pro; ++q) {
+        float wj[SEG]; int pb[SEG];
+        cond_taps(q, wj, pb);
+        input_phase(q, 1, false);
+        __syncthreads();
+        layer_phase<T, 0, 1>(lds, wreg[0], q, wj, pb); __syncthreads();
+        layer_phase<T, 1, 1>(lds, wreg[1], q, wj, pb); __syncthreads();
+        layer_phase<T, 2, 1>(lds, wreg[2], q, wj, pb); __syncthreads();
+        layer_phase<T, 3, 1>(lds, wreg[3], q, wj, pb); __syncthreads();
+        layer_phase<T, 4, 1>(lds, wreg[4], q, wj, pb); __syncthreads();
+        layer_phase<T, 5, 1>(lds, wreg[5], q, wj, pb); __syncthreads();
+    }
+
+    // ---- generation (cswnv_shift1.py:348-402 / dswnv.py:338-374)
+    const __amdgpu_buffer_rsrc_t wsk2 = make_rsrc(P + a.y.wsk2, (unsigned)(L * S * 64 * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t w12 = make_rsrc(P + a.y.w12, (unsigned)(T::O1 * S * sizeof(float)));
+    const __amdgpu_buffer_rsrc_t w22 = make_rsrc(P + a.y.w22, (unsigned)(T::NO * T::O1 * sizeof(float)));
+    input_phase(RF + 1 - SEG, SEG, true);
+    for (int i = 0; i < a.n_steps; ++i) {
+        const int q0 = RF + 1 - SEG + i * SEG;
+        float wj[SEG]; int pb[SEG];
+        cond_taps(q0, wj, pb);
+        // noise for this step is independent of the recurrence: fetch it now
+        float nz[SEG];
+        if (KIND == SWN_KIND_LAPLACE) {
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) nz[j] = a.noise[((size_t)b * a.n_steps + i) * SEG + j];
+        }
+        float sacc[S / 128];
+#pragma unroll
+        for (int ps = 0; ps < S / 128; ++ps) sacc[ps] = 0.f;
+        __syncthreads();
+        layer_phase<T, 0, SEG>(lds, wreg[0], q0, wj, pb); __syncthreads();
+        layer_phase<T, 1, SEG>(lds, wreg[1], q0, wj, pb); skip_slice<T, 0>(lds, wsk2, sacc); __syncthreads();
+        layer_phase<T, 2, SEG>(lds, wreg[2], q0, wj, pb); skip_slice<T, 1>(lds, wsk2, sacc); __syncthreads();
+        layer_phase<T, 3, SEG>(lds, wreg[3], q0, wj, pb); skip_slice<T, 2>(lds, wsk2, sacc); __syncthreads();
+        layer_phase<T, 4, SEG>(lds, wreg[4], q0, wj, pb); skip_slice<T, 3>(lds, wsk2, sacc); __syncthreads();
+        layer_phase<T, 5, SEG>(lds, wreg[5], q0, wj, pb); skip_slice<T, 4>(lds, wsk2, sacc); __syncthreads();
+        skip_slice<T, 5>(lds, wsk2, sacc);
+        {
+            const int hr = tid >> 2, hp = tid & 3;
+#pragma unroll
+            for (int ps = 0; ps < S / 128; ++ps) {
+                const float v = sum4(sacc[ps]);
+                if (hp == 0) lds[T::o_skip + hr + 128 * ps] = fmaxf(v + P[a.y.bsk + hr + 128 * ps], 0.f);
+            }
+        }
+        __syncthreads();
+        tiled_matvec<T::O1, S>(w12, P + a.y.b1, lds + T::o_skip, lds + T::o_o1, true);
+        __syncthreads();
+
+        if (KIND == SWN_KIND_LAPLACE) {
+            if (tid < 64) {
+                // out_2: NO <= 14 rows, 4 lanes per row, weights resident in LDS
+                const int r = tid >> 2, pp = tid & 3;
+                float acc = 0.f;
+                if (r < T::NO) {
+#pragma unroll
+                    for (int mm = 0; mm < S / 16; ++mm) {
+                        const float4 w = *reinterpret_cast<const float4*>(lds + T::o_w2 + r * S + 16 * mm + 4 * pp);
+                        const float4 x = *reinterpret_cast<const float4*>(lds + T::o_o1 + 16 * mm + 4 * pp);
+                        acc = fmaf(w.x, x.x, acc); acc = fmaf(w.y, x.y, acc);
+                        acc = fmaf(w.z, x.z, acc); acc = fmaf(w.w, x.w, acc);
+                    }
+                }
+                acc = sum4(acc);
+                if (r < T::NO) acc += lds[T::o_w2 + T::NO * S + r];
+                if (a.heads && pp == 0 && r < T::NO) a.heads[((size_t)b * a.n_steps + i) * T::NO + r] = acc;
+                float o2[T::NO];
+#pragma unroll
+                for (int e = 0; e < T::NO; ++e) o2[e] = __shfl(acc, 4 * e, 64);
+                if (tid == 0) {
+#pragma clang fp contract(off)
+                    // Laplace head, cswnv_shift1.py:368-391
+                    const float* forced = reinterpret_cast<const float*>(a.forced);
+                    float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * SEG + (size_t)i * SEG;
+                    float lp[T::LPC > 0 ? T::LPC : 1];
+#pragma unroll
+                    for (int k = 0; k < T::LPC; ++k) lp[k] = lds[T::o_hist + T::WN - T::LPC + k];
+                    float fed[SEG];
+#pragma unroll
+                    for (int j = 0; j < SEG; ++j) {
+                        const float mu = o2[j];
+                        const float yv = o2[SEG + j];
+                        const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
+                        float lpv = 0.f;
+#pragma unroll
+                        for (int k = 0; k < T::LPC; ++k) lpv += o2[2 * SEG + T::LPC - 1 - k] * lp[k];
+                        const float e = nz[j];
+                        const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+                        const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
+                        float sv = (T::LPC > 0) ? (lpv + mu) - t : mu - t;
+                        sv = fminf(fmaxf(sv, -1.f), 1.f);
+                        outp[j] = sv;
+                        const float fd = forced ? forced[(size_t)b * a.n_steps * SEG + (size_t)i * SEG + j] : sv;
+                        fed[j] = fd;
+#pragma unroll
+                        for (int k = 0; k + 1 < T::LPC; ++k) lp[k] = lp[k + 1];
+                        if (T::LPC > 0) lp[T::LPC - 1] = fd;
+                    }
+                    float keep[T::WN];
+#pragma unroll
+                    for (int k = 0; k < T::WN; ++k) keep[k] = lds[T::o_hist + k];
+#pragma unroll
+                    for (int k = 0; k + SEG < T::WN; ++k) lds[T::o_hist + k] = keep[k + SEG];
+#pragma unroll
+                    for (int j = 0; j < SEG; ++j) lds[T::o_hist + T::WN - SEG + j] = fed[j];
+                }
+                // the other lanes of wave 0 read the window written by lane 0: same wave, LDS
+                // operations complete in order; keep the compiler from moving the reads up
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        } else {
+            tiled_matvec<T::NO, T::O1>(w22, P + a.y.b2, lds + T::o_o1, lds + T::o_o2, false);
+            __syncthreads();
+            if (a.heads)
+                for (int e = tid; e < T::NO; e += NT) a.heads[((size_t)b * a.n_steps + i) * T::NO + e] = lds[T::o_o2 + e];
+            if (tid < 64) {
+                // softmax head, dswnv.py:361-369
+                constexpr int Q = T::Q;
+                const float* o2v = lds + T::o_o2;
+                const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
+                float m = -INFINITY;
+                for (int e = tid; e < Q; e += 64) m = fmaxf(m, o2v[e]);
+                for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
+                float sum = 0.f;
+                for (int e = tid; e < Q; e += 64) sum += expf(o2v[e] - m);
+                for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+                float sum2 = 0.f;
+                for (int e = tid; e < Q; e += 64) sum2 += expf(o2v[e] - m) / sum;
+                for (int d = 32; d >= 1; d >>= 1) sum2 += __shfl_xor(sum2, d, 64);
+                float best = -1.f; int bi = 0x7fffffff;
+                for (int e = tid; e < Q; e += 64) {
+                    const float r = ((expf(o2v[e] - m) / sum) / sum2) / qn[e];
+                    if (r > best) { best = r; bi = e; }
+                }
+                for (int d = 32; d >= 1; d >>= 1) {
+                    const float ob = __shfl_xor(best, d, 64);
+                    const int oi = __shfl_xor(bi, d, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (tid == 0) {
+                    const int* forced = reinterpret_cast<const int*>(a.forced);
+                    reinterpret_cast<int*>(a.out)[(size_t)b * a.n_steps + i] = bi;
+                    const int fd = forced ? forced[(size_t)b * a.n_steps + i] : bi;
+#pragma unroll
+                    for (int k = 0; k + 1 < T::WN; ++k) ihist[k] = ihist[k + 1];
+                    ihist[T::WN - 1] = fd;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+        }
+        // next step's input layer, still inside wave 0 (no barrier between sampling and h0)
+        if (i + 1 < a.n_steps) input_phase(q0 + SEG, SEG, true);
+    }
+}
+
+template <class T>
+int launch(const B6Args& a, hipStream_t st) {
+    static_assert(T::lds_bytes <= 160 * 1024, "LDS budget");
+    auto kern = decode_bl6_kernel<T>;
+    if (T::lds_bytes > 64 * 1024) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)T::lds_bytes) != hipSuccess)
+            return SWN_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.B), dim3(NT), T::lds_bytes, st, a);
+    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, const float* cond, int batch,
+                                  int n_frames, int n_steps, const float* noise, const void* forced,
+                                  void* out, float* heads, void* stream_) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    if (rc < 0) return rc;
+    if (!g.bl6 || g.U > 256 || g.U < 2 * g.seg || g.audio_in) return SWN_E_UNSUPPORTED;
+    B6Args a;
+    swn_make_layout(&g, &a.y);
+    a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.out = out; a.heads = heads;
+    a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.U = g.U; a.N = g.N;
+    hipStream_t st = (hipStream_t)stream_;
+    if (g.kind == SWN_KIND_LAPLACE && g.S == 128) {
+        if (g.seg == 1 && g.lpc == 0) return launch<Tr<128, 1, 0, SWN_KIND_LAPLACE, 0>>(a, st);
+        if (g.seg == 1 && g.lpc == 4) return launch<Tr<128, 1, 4, SWN_KIND_LAPLACE, 0>>(a, st);
+        if (g.seg == 2 && g.lpc == 4) return launch<Tr<128, 2, 4, SWN_KIND_LAPLACE, 0>>(a, st);
+        if (g.seg == 5 && g.lpc == 0) return launch<Tr<128, 5, 0, SWN_KIND_LAPLACE, 0>>(a, st);
+        if (g.seg == 5 && g.lpc == 4) return launch<Tr<128, 5, 4, SWN_KIND_LAPLACE, 0>>(a, st);
+    }
+    if (g.kind == SWN_KIND_SOFTMAX && g.S == 256 && g.Q == 256)
+        return launch<Tr<256, 1, 0, SWN_KIND_SOFTMAX, 256>>(a, st);
     return SWN_E_UNSUPPORTED;
 }

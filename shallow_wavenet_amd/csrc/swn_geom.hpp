@@ -28,6 +28,7 @@ struct SwnGeom {
     int Hp;        // H rounded up to 4 (row stride of every H-vector)
     int Sp, O1p, A0p;
     int N;         // conditioning row width per frame: L*seg*2H
+    int bl6;       // 1 when the stack is the BASELINE-literal 1x6, H=64, K=2 shape (fast decode kernel)
     int dil[SWN_MAXL];
     int pad[SWN_MAXL];
     int aux_cin[SWN_MAXAUX], aux_cout[SWN_MAXAUX], aux_dil[SWN_MAXAUX], aux_pad[SWN_MAXAUX];
@@ -50,6 +51,11 @@ struct SwnLayout {
     size_t wsk, bsk;                         // [S][L*Hp], [S] (biases summed over layers)
     size_t w1, b1;                           // [O1][Sp], [O1]
     size_t w2, b2;                           // [NO][O1p], [NO]
+    // ---- lane-tiled copies for the BL6-class decode kernel (bl6 only)
+    size_t wd2;                              // [L][512 threads][2 rows][16]   register-resident dil_h
+    size_t wsk2;                             // [L][4][S][4][4]   out_skip, 4 lanes per row
+    size_t w12;                              // [S/16][O1][4][4]  out_1
+    size_t w22;                              // [O1/16][NO][4][4] out_2 (softmax only)
     size_t total;
 };
 
@@ -94,6 +100,8 @@ static inline __host__ int swn_make_geom(const swn_net_desc* d, SwnGeom* g) {
     g->Hp = swn_round4(g->H); g->Sp = swn_round4(g->S); g->O1p = swn_round4(g->O1);
     g->A0p = swn_round4(g->A0);
     g->N = L * g->seg * 2 * g->H;
+    g->bl6 = (g->H == 64 && g->K == 2 && d->dilation_depth == 6 && d->dilation_repeat == 1 &&
+              (g->S % 16) == 0 && (g->O1 % 16) == 0) ? 1 : 0;
     return SWN_OK;
 }
 
@@ -129,6 +137,13 @@ static inline __host__ void swn_make_layout(const SwnGeom* g, SwnLayout* y) {
     y->b1 = o; o = swn_al(o + g->O1);
     y->w2 = o; o = swn_al(o + (size_t)g->NO * g->O1p);
     y->b2 = o; o = swn_al(o + g->NO);
+    y->wd2 = y->wsk2 = y->w12 = y->w22 = o;
+    if (g->bl6) {
+        y->wd2 = o; o = swn_al(o + (size_t)g->L * 512 * 32);
+        y->wsk2 = o; o = swn_al(o + (size_t)g->L * g->S * 64);
+        y->w12 = o; o = swn_al(o + (size_t)g->O1 * g->S);
+        y->w22 = o; if (g->kind == SWN_KIND_SOFTMAX) o = swn_al(o + (size_t)g->NO * g->O1);
+    }
     y->total = o;
 }
 

@@ -125,6 +125,19 @@ extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int
                 for (int k = 0; k < K; ++k)
                     out[y.wd + (((size_t)l * H2 + o) * K + k) * g.Hp + i] = w[((size_t)o * H + i) * K + k];
         memcpy(out + y.bd + (size_t)l * H2, b, sizeof(float) * H2);
+        if (g.bl6) {
+            // thread t = o*8+p keeps rows (o, o+H); element 4m+e is input j = 32m+4p+e of [tap0|tap1]
+            for (int tt = 0; tt < 512; ++tt) {
+                const int o = tt >> 3, p = tt & 7;
+                for (int r = 0; r < 2; ++r)
+                    for (int m = 0; m < 4; ++m)
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = 32 * m + 4 * p + e, k = j / H, i = j % H;
+                            out[y.wd2 + (((size_t)l * 512 + tt) * 2 + r) * 16 + 4 * m + e] =
+                                w[((size_t)(o + r * H) * H + i) * K + k];
+                        }
+            }
+        }
     }
     // ---- skip 1x1s concatenated along the input axis, biases summed
     std::vector<double> bs(S, 0.0);
@@ -132,8 +145,12 @@ extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int
         const float* w = t[ti++];       // (S, H, 1)
         const float* b = t[ti++];
         for (int c = 0; c < S; ++c) {
-            for (int i = 0; i < H; ++i)
+            for (int i = 0; i < H; ++i) {
                 out[y.wsk + (size_t)c * L * g.Hp + (size_t)l * g.Hp + i] = w[(size_t)c * H + i];
+                if (g.bl6)   // [l][mm][row][pp][e], input i = 16mm+4pp+e
+                    out[y.wsk2 + ((((size_t)l * 4 + i / 16) * S + c) * 4 + (i % 16) / 4) * 4 + (i % 4)] =
+                        w[(size_t)c * H + i];
+            }
             bs[c] += b[c];
         }
     }
@@ -144,12 +161,22 @@ extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int
         for (int o = 0; o < g.O1; ++o)
             memcpy(out + y.w1 + (size_t)o * g.Sp, w + (size_t)o * S, sizeof(float) * S);
         memcpy(out + y.b1, b, sizeof(float) * g.O1);
+        if (g.bl6)
+            for (int o = 0; o < g.O1; ++o)
+                for (int c = 0; c < S; ++c)
+                    out[y.w12 + ((((size_t)(c / 16)) * g.O1 + o) * 4 + (c % 16) / 4) * 4 + (c % 4)] =
+                        w[(size_t)o * S + c];
     }
     {
         const float* w = t[ti++]; const float* b = t[ti++];      // (NO, O1, 1)
         for (int o = 0; o < g.NO; ++o)
             memcpy(out + y.w2 + (size_t)o * g.O1p, w + (size_t)o * g.O1, sizeof(float) * g.O1);
         memcpy(out + y.b2, b, sizeof(float) * g.NO);
+        if (g.bl6 && g.kind == SWN_KIND_SOFTMAX)
+            for (int o = 0; o < g.NO; ++o)
+                for (int c = 0; c < g.O1; ++c)
+                    out[y.w22 + ((((size_t)(c / 16)) * g.NO + o) * 4 + (c % 16) / 4) * 4 + (c % 4)] =
+                        w[(size_t)o * g.O1 + c];
     }
     return ti == n_tensors ? SWN_OK : SWN_E_BADARG;
 }
