@@ -119,7 +119,7 @@ int    swn_decode(const swn_net_desc* d, const float* packed_dev, const float* c
  *   work_dev    swn_forward_work_floats() scratch (hidden states, skip accumulator)
  *   out_dev     (B, n_out, Tp) raw out_2 outputs, Tp = T - 2*seg + 1 (softmax: T - 1);
  *               the host splits mu / log b / a (cswnv_shift1.py:228-267)
- *   hs_dev      optional (L+1, B, H, Tp) hidden states h_0..h_L for backward / tests      */
+ *   hs_dev      optional (B, L+1, H, Tp) hidden states h_0..h_L for backward / tests      */
 size_t swn_forward_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_forward(const swn_net_desc* d, const float* packed_dev, const float* cond_dev,
                    const void* audio_dev, int batch, int n_frames, float* work_dev,

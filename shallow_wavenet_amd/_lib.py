@@ -14,7 +14,7 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_
 from .config import NetConfig
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswn_hip.so")
+LIB_PATH = os.environ.get("SWN_HIP_LIB", os.path.join(_HERE, "libswn_hip.so"))   # override: diagnostic builds
 CSRC = os.path.join(_HERE, "csrc")
 
 _lock = threading.Lock()

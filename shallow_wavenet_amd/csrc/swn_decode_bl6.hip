@@ -25,6 +25,11 @@ constexpr int NT = 512;
 constexpr int H = 64;
 constexpr int L = 6;
 constexpr int RF = 64;
+#ifdef SWN_STAMP
+constexpr bool HEADS_ON = false;
+#else
+constexpr bool HEADS_ON = true;
+#endif
 
 struct B6Args {
     const float* P;
@@ -62,7 +67,8 @@ struct Tr {
     static constexpr int o_o1 = o_skip + S_;
     static constexpr int o_o2 = o_o1 + O1;
     static constexpr int o_hist = o_o2 + r4(NO);
-    static constexpr int o_cz = o_hist + r4(WN);          // cb[64], cv[2][64], cc[2][64]
+    static constexpr int o_tnz = o_hist + r4(WN);         // [2][8] Laplace deviates of the next step
+    static constexpr int o_cz = o_tnz + 16;               // cb[64], cv[2][64], cc[2][64]
     static constexpr int o_w2 = o_cz + 5 * H;             // laplace: out_2 rows [NO][S] (+b2)
     static constexpr int o_wl = o_w2 + (KIND_ == SWN_KIND_LAPLACE ? NO * S_ + r4(NO) : 0);   // [L-NREG][8][512][4]
     static constexpr int o_end = o_wl + (L - NREG) * 8 * NT * 4;
@@ -92,8 +98,25 @@ __device__ __forceinline__ float sum8(float v) {      // all 8 lanes of an align
     v += dpp_f<0x141>(v);     // row_half_mirror
     return v;
 }
-__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
-__device__ __forceinline__ float ssign(float x) { return x / (1.f + fabsf(x)); }
+// exp(x) = 2^(x*log2e) on the transcendental unit; the product's rounding error is fed back as a
+// first-order correction, so the result stays within ~1.5 ulp (libm-grade) at 6 instructions.
+__device__ __forceinline__ float exp_c(float x) {
+    const float t = x * 1.44269504f;
+    const float lo = fmaf(x, 1.44269504f, -t) + x * 1.92596299e-8f;
+    const float e = __builtin_amdgcn_exp2f(t);
+    return fmaf(e, lo * 0.693147181f, e);
+}
+__device__ __forceinline__ float rcp_c(float x) {        // v_rcp_f32 + one Newton step (<= 1 ulp)
+    const float r = __builtin_amdgcn_rcpf(x);
+    return fmaf(r, fmaf(-x, r, 1.f), r);
+}
+__device__ __forceinline__ float sigm(float x) { return rcp_c(1.f + exp_c(-x)); }
+__device__ __forceinline__ float tanh_c(float x) {        // (1 - e^-2|x|) / (1 + e^-2|x|), abs error ~1e-7
+    if (fabsf(x) > 9.02f) return copysignf(1.f, x);    // saturated in fp32 (also keeps this a branchy block)
+    const float t = exp_c(-2.f * fabsf(x));
+    return copysignf((1.f - t) * rcp_c(1.f + t), x);
+}
+__device__ __forceinline__ float ssign(float x) { return x * rcp_c(1.f + fabsf(x)); }
 
 template <int NP>
 __device__ __forceinline__ float pick(const float (&a)[NP], int p) {
@@ -140,6 +163,7 @@ __device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float
     }
 #pragma unroll
     for (int j = 0; j < NP; ++j) { az[j] = sum8(az[j]); ac[j] = sum8(ac[j]); }
+    __builtin_amdgcn_sched_barrier(0);              // keep the gate epilogue behind the reduction
     if (p < NP) {                                   // lane p finishes position q0+p
         const int q = q0 + p;
         const float sz = pick<NP>(az, p) + lds[T::o_bd + LAYER * 2 * H + o];
@@ -153,7 +177,7 @@ __device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float
             gc = fmaf(wj[s], pr[H + o], gc);
         }
         const float z = sigm(gz * sz);
-        const float c = tanhf(gc * sc);
+        const float c = tanh_c(gc * sc);
         const float hp = ring[(q & (R - 1)) * H + o];
         const float hn = (1.f - z) * c + z * hp;
         if (LAYER + 1 < L) {
@@ -162,6 +186,7 @@ __device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float
         }
         if (p == NP - 1) lds[T::o_hcat + LAYER * H + o] = hn;
     }
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 // out_skip slice of one layer, 4 lanes per row, weights streamed from the lane-tiled copy.
@@ -229,9 +254,6 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
         for (int e = tid; e < T::NO * S; e += NT) lds[T::o_w2 + e] = P[a.y.w2 + (size_t)(e / S) * r4(S) + (e % S)];
         for (int e = tid; e < T::NO; e += NT) lds[T::o_w2 + T::NO * S + e] = P[a.y.b2 + e];
     }
-    int* ihist = reinterpret_cast<int*>(lds + T::o_hist);
-    if (KIND == SWN_KIND_SOFTMAX)
-        for (int e = tid; e < T::WN; e += NT) ihist[e] = T::Q / 2;
     // conditioning frames are copied 16 B per lane through a buffer resource (32-bit offsets)
     const __amdgpu_buffer_rsrc_t condr =
         make_rsrc(a.cond + (size_t)b * a.Tf * a.N, (unsigned)((size_t)a.Tf * a.N * sizeof(float)));
@@ -289,40 +311,74 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
         }
     };
 
-    // input layer h0 = softsign(causal(lift(S)))  (wave 0; fused wav_conv+causal taps)
-    auto input_phase = [&](int q0, int np, bool gen) {
+    // input layer h0 = softsign(causal(lift(S)))  (wave 0; fused wav_conv+causal taps).
+    // Prologue form: all seed samples are zero / the mu-law zero index, only tap validity matters.
+#define c_b  lds[T::o_cz + o]
+#define c_v0 lds[T::o_cz + H + o]
+#define c_v1 lds[T::o_cz + 2 * H + o]
+#define c_c0 lds[T::o_cz + 3 * H + o]
+#define c_c1 lds[T::o_cz + 4 * H + o]
+    auto input_seed = [&](int q) {
         if (tid < H) {
             const int o = tid;
             constexpr int R0 = T::ring_len(0);
-            for (int j = 0; j < np; ++j) {
-                const int q = q0 + j;
-                const int qe = q0 + np - 1;
-                float acc = lds[T::o_cz + o];
+            float acc = c_b;
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
-                    const int r = q - (1 - k);
-                    if (KIND == SWN_KIND_LAPLACE) {
-                        if (r >= -(SEG - 1)) {
-                            const float sv = gen ? lds[T::o_hist + r - qe + T::WN - 1] : 0.f;
-                            acc += fmaf(lds[T::o_cz + H + k * H + o], sv, lds[T::o_cz + 3 * H + k * H + o]);
-                        }
-                    } else {
-                        if (r >= 0) {
-                            const int idx = gen ? ihist[r - qe + T::WN - 1] : T::Q / 2;
-                            acc += P[a.y.ct + ((size_t)k * T::Q + idx) * H + o];
-                        }
-                    }
+            for (int k = 0; k < 2; ++k) {
+                const int r = q - (1 - k);
+                if (KIND == SWN_KIND_LAPLACE) {
+                    if (r >= -(SEG - 1)) acc += fmaf(k ? c_v1 : c_v0, 0.f, k ? c_c1 : c_c0);
+                } else {
+                    if (r >= 0) acc += P[a.y.ct + ((size_t)k * T::Q + T::Q / 2) * H + o];
                 }
-                lds[T::o_ring + (q & (R0 - 1)) * H + o] = ssign(acc);
             }
+            lds[T::o_ring + (q & (R0 - 1)) * H + o] = ssign(acc);
+        }
+    };
+    // Generation form: the sample window lives in registers of wave 0 (uniform across its lanes):
+    // win[] = S[qe-WN+1 .. qe], qe = last position whose input sample is known.
+    constexpr int WNF = KIND == SWN_KIND_LAPLACE ? T::WN : 1, WNI = KIND == SWN_KIND_SOFTMAX ? T::WN : 1;
+    float win[WNF];
+    int iwin[WNI];
+#pragma unroll
+    for (int k = 0; k < WNF; ++k) win[k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < WNI; ++k) iwin[k] = T::Q / 2;
+    auto input_gen = [&](int q0n) {
+        if (tid < H) {
+            const int o = tid;
+            constexpr int R0 = T::ring_len(0);
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) {
+                float acc = c_b;
+                if constexpr (KIND == SWN_KIND_LAPLACE) {
+                    acc += fmaf(c_v0, win[T::WN - SEG + j - 1], c_c0);
+                    acc += fmaf(c_v1, win[T::WN - SEG + j], c_c1);
+                } else {
+                    acc += P[a.y.ct + ((size_t)0 * T::Q + iwin[T::WN - SEG + j - 1]) * H + o];
+                    acc += P[a.y.ct + ((size_t)1 * T::Q + iwin[T::WN - SEG + j]) * H + o];
+                }
+                lds[T::o_ring + ((q0n + j) & (R0 - 1)) * H + o] = ssign(acc);
+            }
+        }
+    };
+    // Laplace deviate of the uniform draw, -> LDS slot of step `step` (computed by wave 1, off the
+    // critical path): tn = sign(e) * log1p(-2|e|)   (cswnv_shift1.py:374-376)
+    auto noise_ahead = [&](int step) {
+        if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG && step < a.n_steps) {
+            const int j = tid - 64;
+            const float e = a.noise[((size_t)b * a.n_steps + step) * SEG + j];
+            const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+            lds[T::o_tnz + (step & 1) * 8 + j] = sg * log1pf(-2.f * fabsf(e));
         }
     };
 
     // ---- prologue: seed positions 0..rf-seg, one position per pass (cswnv_shift1.py:321-334)
+#pragma unroll 1
     for (int q = 0; q < n_pro; ++q) {
         float wj[SEG]; int pb[SEG];
         cond_taps(q, wj, pb);
-        input_phase(q, 1, false);
+        input_seed(q);
         __syncthreads();
         layer_phase<T, 0, 1>(lds, wreg[0], q, wj, pb); __syncthreads();
         layer_phase<T, 1, 1>(lds, wreg[1], q, wj, pb); __syncthreads();
@@ -336,27 +392,35 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     const __amdgpu_buffer_rsrc_t wsk2 = make_rsrc(P + a.y.wsk2, (unsigned)(L * S * 64 * sizeof(float)));
     const __amdgpu_buffer_rsrc_t w12 = make_rsrc(P + a.y.w12, (unsigned)(T::O1 * S * sizeof(float)));
     const __amdgpu_buffer_rsrc_t w22 = make_rsrc(P + a.y.w22, (unsigned)(T::NO * T::O1 * sizeof(float)));
-    input_phase(RF + 1 - SEG, SEG, true);
+#ifdef SWN_STAMP
+    // diagnostic build only (tools/stamp_decode.py): per-phase cycle sums of wave 0 leave the kernel
+    // through the `heads` debug buffer, which this build writes nothing else into.
+    unsigned long long tacc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = 0;
+#define STAMP(k) { const unsigned long long tn = __builtin_amdgcn_s_memtime(); tacc[k] += tn - tprev; tprev = tn; }
+#else
+#define STAMP(k)
+#endif
+    input_gen(RF + 1 - SEG);
+    noise_ahead(0);       // visible to wave 0 after the barriers of step 0
+#pragma unroll 1
     for (int i = 0; i < a.n_steps; ++i) {
         const int q0 = RF + 1 - SEG + i * SEG;
         float wj[SEG]; int pb[SEG];
+#ifdef SWN_STAMP
+        tprev = __builtin_amdgcn_s_memtime();
+#endif
         cond_taps(q0, wj, pb);
-        // noise for this step is independent of the recurrence: fetch it now
-        float nz[SEG];
-        if (KIND == SWN_KIND_LAPLACE) {
-#pragma unroll
-            for (int j = 0; j < SEG; ++j) nz[j] = a.noise[((size_t)b * a.n_steps + i) * SEG + j];
-        }
         float sacc[S / 128];
 #pragma unroll
         for (int ps = 0; ps < S / 128; ++ps) sacc[ps] = 0.f;
-        __syncthreads();
-        layer_phase<T, 0, SEG>(lds, wreg[0], q0, wj, pb); __syncthreads();
-        layer_phase<T, 1, SEG>(lds, wreg[1], q0, wj, pb); skip_slice<T, 0>(lds, wsk2, sacc); __syncthreads();
-        layer_phase<T, 2, SEG>(lds, wreg[2], q0, wj, pb); skip_slice<T, 1>(lds, wsk2, sacc); __syncthreads();
-        layer_phase<T, 3, SEG>(lds, wreg[3], q0, wj, pb); skip_slice<T, 2>(lds, wsk2, sacc); __syncthreads();
-        layer_phase<T, 4, SEG>(lds, wreg[4], q0, wj, pb); skip_slice<T, 3>(lds, wsk2, sacc); __syncthreads();
-        layer_phase<T, 5, SEG>(lds, wreg[5], q0, wj, pb); skip_slice<T, 4>(lds, wsk2, sacc); __syncthreads();
+        __syncthreads(); STAMP(0)
+        layer_phase<T, 0, SEG>(lds, wreg[0], q0, wj, pb); __syncthreads(); STAMP(1)
+        layer_phase<T, 1, SEG>(lds, wreg[1], q0, wj, pb); skip_slice<T, 0>(lds, wsk2, sacc); __syncthreads(); STAMP(2)
+        layer_phase<T, 2, SEG>(lds, wreg[2], q0, wj, pb); skip_slice<T, 1>(lds, wsk2, sacc); __syncthreads(); STAMP(3)
+        layer_phase<T, 3, SEG>(lds, wreg[3], q0, wj, pb); skip_slice<T, 2>(lds, wsk2, sacc); __syncthreads(); STAMP(4)
+        layer_phase<T, 4, SEG>(lds, wreg[4], q0, wj, pb); skip_slice<T, 3>(lds, wsk2, sacc); __syncthreads(); STAMP(5)
+        layer_phase<T, 5, SEG>(lds, wreg[5], q0, wj, pb); skip_slice<T, 4>(lds, wsk2, sacc); __syncthreads(); STAMP(6)
         skip_slice<T, 5>(lds, wsk2, sacc);
         {
             const int hr = tid >> 2, hp = tid & 3;
@@ -366,9 +430,12 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                 if (hp == 0) lds[T::o_skip + hr + 128 * ps] = fmaxf(v + P[a.y.bsk + hr + 128 * ps], 0.f);
             }
         }
-        __syncthreads();
+        __syncthreads(); STAMP(7)
+        // wave 1 prepares the next step's Laplace deviates while the out_1 weights are in flight; wave 0
+        // left the previous tail long ago, so the slot it overwrites ((i+1)&1 == (i-1)&1) is free
+        noise_ahead(i + 1);
         tiled_matvec<T::O1, S>(w12, P + a.y.b1, lds + T::o_skip, lds + T::o_o1, true);
-        __syncthreads();
+        __syncthreads(); STAMP(8)
 
         if (KIND == SWN_KIND_LAPLACE) {
             if (tid < 64) {
@@ -386,57 +453,41 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                 }
                 acc = sum4(acc);
                 if (r < T::NO) acc += lds[T::o_w2 + T::NO * S + r];
-                if (a.heads && pp == 0 && r < T::NO) a.heads[((size_t)b * a.n_steps + i) * T::NO + r] = acc;
-                float o2[T::NO];
-#pragma unroll
-                for (int e = 0; e < T::NO; ++e) o2[e] = __shfl(acc, 4 * e, 64);
-                if (tid == 0) {
-#pragma clang fp contract(off)
-                    // Laplace head, cswnv_shift1.py:368-391
-                    const float* forced = reinterpret_cast<const float*>(a.forced);
-                    float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * SEG + (size_t)i * SEG;
-                    float lp[T::LPC > 0 ? T::LPC : 1];
-#pragma unroll
-                    for (int k = 0; k < T::LPC; ++k) lp[k] = lds[T::o_hist + T::WN - T::LPC + k];
-                    float fed[SEG];
-#pragma unroll
-                    for (int j = 0; j < SEG; ++j) {
-                        const float mu = o2[j];
-                        const float yv = o2[SEG + j];
-                        const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
-                        float lpv = 0.f;
-#pragma unroll
-                        for (int k = 0; k < T::LPC; ++k) lpv += o2[2 * SEG + T::LPC - 1 - k] * lp[k];
-                        const float e = nz[j];
-                        const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
-                        const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
-                        float sv = (T::LPC > 0) ? (lpv + mu) - t : mu - t;
-                        sv = fminf(fmaxf(sv, -1.f), 1.f);
-                        outp[j] = sv;
-                        const float fd = forced ? forced[(size_t)b * a.n_steps * SEG + (size_t)i * SEG + j] : sv;
-                        fed[j] = fd;
-#pragma unroll
-                        for (int k = 0; k + 1 < T::LPC; ++k) lp[k] = lp[k + 1];
-                        if (T::LPC > 0) lp[T::LPC - 1] = fd;
-                    }
-                    float keep[T::WN];
-#pragma unroll
-                    for (int k = 0; k < T::WN; ++k) keep[k] = lds[T::o_hist + k];
-#pragma unroll
-                    for (int k = 0; k + SEG < T::WN; ++k) lds[T::o_hist + k] = keep[k + SEG];
-#pragma unroll
-                    for (int j = 0; j < SEG; ++j) lds[T::o_hist + T::WN - SEG + j] = fed[j];
-                }
-                // the other lanes of wave 0 read the window written by lane 0: same wave, LDS
-                // operations complete in order; keep the compiler from moving the reads up
+                if (HEADS_ON && a.heads && pp == 0 && r < T::NO) a.heads[((size_t)b * a.n_steps + i) * T::NO + r] = acc;
+                // park the NO head outputs in LDS; every lane re-reads them (same wave: LDS ops are in
+                // order, the fences only pin the compiler)
+                if (pp == 0 && r < T::NO) lds[T::o_o2 + r] = acc;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const float* o2 = lds + T::o_o2;
+                {
+#pragma clang fp contract(off)
+                    // Laplace head, cswnv_shift1.py:368-391, evaluated uniformly by every lane of wave 0
+                    // so the new samples are in registers for the next input layer (no LDS round trip).
+                    float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * SEG + (size_t)i * SEG;
+#pragma unroll
+                    for (int j = 0; j < SEG; ++j) {
+                        const float mu = o2[j];
+                        const float bsc = sigm(o2[SEG + j]);                 // exp(logsigmoid(y))
+                        float lpv = 0.f;
+#pragma unroll
+                        for (int k = 0; k < T::LPC; ++k) lpv += o2[2 * SEG + T::LPC - 1 - k] * win[T::WN - T::LPC + k];
+                        const float t = bsc * lds[T::o_tnz + (i & 1) * 8 + j];
+                        float sv = (T::LPC > 0) ? (lpv + mu) - t : mu - t;
+                        sv = fminf(fmaxf(sv, -1.f), 1.f);
+                        if (tid == 0) outp[j] = sv;
+                        const float fd = a.forced ? reinterpret_cast<const float*>(a.forced)[((size_t)b * a.n_steps + i) * SEG + j] : sv;
+#pragma unroll
+                        for (int k = 0; k + 1 < T::WN; ++k) win[k] = win[k + 1];
+                        win[T::WN - 1] = fd;
+                    }
+                }
             }
         } else {
             tiled_matvec<T::NO, T::O1>(w22, P + a.y.b2, lds + T::o_o1, lds + T::o_o2, false);
             __syncthreads();
-            if (a.heads)
+            if (HEADS_ON && a.heads)
                 for (int e = tid; e < T::NO; e += NT) a.heads[((size_t)b * a.n_steps + i) * T::NO + e] = lds[T::o_o2 + e];
             if (tid < 64) {
                 // softmax head, dswnv.py:361-369
@@ -462,22 +513,21 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                     const int oi = __shfl_xor(bi, d, 64);
                     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
                 }
-                if (tid == 0) {
-                    const int* forced = reinterpret_cast<const int*>(a.forced);
-                    reinterpret_cast<int*>(a.out)[(size_t)b * a.n_steps + i] = bi;
-                    const int fd = forced ? forced[(size_t)b * a.n_steps + i] : bi;
+                if (tid == 0) reinterpret_cast<int*>(a.out)[(size_t)b * a.n_steps + i] = bi;
+                const int fd = a.forced ? reinterpret_cast<const int*>(a.forced)[(size_t)b * a.n_steps + i] : bi;
 #pragma unroll
-                    for (int k = 0; k + 1 < T::WN; ++k) ihist[k] = ihist[k + 1];
-                    ihist[T::WN - 1] = fd;
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                for (int k = 0; k + 1 < T::WN; ++k) iwin[k] = iwin[k + 1];
+                iwin[T::WN - 1] = fd;
             }
         }
         // next step's input layer, still inside wave 0 (no barrier between sampling and h0)
-        if (i + 1 < a.n_steps) input_phase(q0 + SEG, SEG, true);
+        if (i + 1 < a.n_steps) input_gen(q0 + SEG);
+        STAMP(9)
     }
+#ifdef SWN_STAMP
+    if (tid == 0 && b == 0 && a.heads)
+        for (int k = 0; k < 10; ++k) a.heads[k] = (float)((double)tacc[k] / (double)a.n_steps);
+#endif
 }
 
 template <class T>

@@ -1,14 +1,286 @@
-// placeholder: teacher-forced stack kernels are added next.
+// Teacher-forced dilated stack on gfx950 (CSWNV.forward cswnv_shift1.py:191-267,
+// DSWNV.forward dswnv.py:250-276): all T positions in parallel, layer by layer.
+//
+// fp32 reference-parity path (this file):
+//   input layer   h0 = softsign(causal(lift(audio)))        fused wav_conv + causal taps / gather table
+//   layer l       a = Wd_l (*) h_{l-1}  (dilated causal conv as a GEMM over K shifted copies of h)
+//                 g = in_x_l(x) (.) a ; z = sigmoid(g[:H]) ; h_l = (1-z) tanh(g[H:]) + z h_{l-1}
+//                 -- gate, highway and the hoisted conditioning fused into the GEMM epilogue --
+//   head          relu(Wsk . [h_1 .. h_L] + bsk) -> relu(W1 . + b1) -> W2 . + b2
+//                 (the six out_skip 1x1s are ONE GEMM over the concatenated hidden states)
+// Hidden states are kept as (B, L+1, H, Tp) so the head reads them as one (L*H)-channel tensor and
+// a backward pass can reuse them.  Every product is an fp32 fma chain in ascending-k order.
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
 
-extern "C" size_t swn_forward_work_floats(const swn_net_desc*, int, int) { return 0; }
-extern "C" int swn_forward(const swn_net_desc*, const float*, const float*, const void*, int, int,
-                           float*, float*, float*, void*) {
-    return SWN_E_UNSUPPORTED;
+namespace {
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ float ssign(float x) { return x / (1.f + fabsf(x)); }
+
+struct FwdArgs {
+    SwnGeom g;
+    SwnLayout y;
+    const float* P;
+    const float* cond;
+    const void* audio;
+    float* hs;        // (B, L+1, H, Tp)
+    int B, Tf, Tp, coff;   // coff: conditioning offset (seg for laplace, 1 for softmax)
+};
+
+// ---- input layer -------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void tf_input_kernel(const FwdArgs a) {
+    const SwnGeom& g = a.g;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.z;
+    if (t >= a.Tp) return;
+    const float* P = a.P;
+    float* h0 = a.hs + (size_t)b * (g.L + 1) * g.H * a.Tp;
+    const int K = g.K, H = g.H;
+    if (KIND == SWN_KIND_LAPLACE) {
+        const float* au = reinterpret_cast<const float*>(a.audio) + (size_t)b * (a.Tp + g.seg - 1);
+        const int ai = t + g.seg - 1;                       // causal output index, cswnv_shift1.py:205
+        for (int o = blockIdx.y; o < H; o += gridDim.y) {
+            float acc = P[a.y.cb + o];
+            for (int k = 0; k < K; ++k) {
+                const int r = ai - (K - 1 - k);
+                if (r >= 0) acc += fmaf(P[a.y.cv + (size_t)k * H + o], au[r], P[a.y.cc + (size_t)k * H + o]);
+            }
+            h0[(size_t)o * a.Tp + t] = ssign(acc);
+        }
+    } else {
+        const int* au = reinterpret_cast<const int*>(a.audio) + (size_t)b * a.Tp;
+        for (int o = blockIdx.y; o < H; o += gridDim.y) {
+            float acc = P[a.y.cb + o];
+            for (int k = 0; k < K; ++k) {
+                const int r = t - (K - 1 - k);
+                if (r >= 0) {
+                    int idx = au[r] % g.Q; idx = idx < 0 ? idx + g.Q : idx;     // OneHot applies x % depth
+                    acc += P[a.y.ct + ((size_t)k * g.Q + idx) * H + o];
+                }
+            }
+            h0[(size_t)o * a.Tp + t] = ssign(acc);
+        }
+    }
 }
+
+// ---- one gated layer: 64 positions x (32 gate rows + 32 candidate rows) per workgroup ----------
+// GEMM over Kd = K*H with the B operand = K dilated shifts of h_{l-1}; BK = 16; thread = 4 positions
+// x (2 gate + 2 candidate rows); fused epilogue writes h_l.
+template <int KIND>
+__global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const int l) {
+    __shared__ float As[16][64 + 4];      // [k][tile row]: rows 0..31 gate, 32..63 candidate
+    __shared__ float Bs[16][64 + 4];      // [k][position]
+    const SwnGeom& g = a.g;
+    const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg;
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 64, o0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;               // tx: 4 positions, ty: 2+2 rows
+    const int dil = g.dil[l];
+    const float* P = a.P;
+    const float* hprev = a.hs + ((size_t)b * (g.L + 1) + l) * H * a.Tp;
+    float* hnext = a.hs + ((size_t)b * (g.L + 1) + l + 1) * H * a.Tp;
+    const float* W = P + a.y.wd + (size_t)l * H2 * K * Hp;            // [o2][k][i]
+    float acc[4][4] = {};                                               // [row: z0,z1,c0,c1][pos]
+    const int Kd = K * Hp;
+    for (int k0 = 0; k0 < Kd; k0 += 16) {
+        {   // A tile: 64 rows x 16 k, k contiguous in memory
+            const int rr = tid >> 2, kq = (tid & 3) * 4;
+            const int o = o0 + (rr & 31);
+            const int row = (rr < 32) ? o : H + o;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (o < H && k0 + kq < Kd) v = *reinterpret_cast<const float4*>(W + (size_t)row * Kd + k0 + kq);
+            As[kq + 0][rr] = v.x; As[kq + 1][rr] = v.y; As[kq + 2][rr] = v.z; As[kq + 3][rr] = v.w;
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {   // B tile: shifted rows of h_{l-1}
+            const int kk = e >> 6, tt = e & 63;
+            const int kd = k0 + kk;
+            const int tap = kd / Hp, i = kd - tap * Hp;
+            const int ts = t0 + tt - (K - 1 - tap) * dil;
+            Bs[kk][tt] = (kd < Kd && i < H && ts >= 0 && t0 + tt < a.Tp) ? hprev[(size_t)i * a.Tp + ts] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float2 az = *reinterpret_cast<const float2*>(&As[kk][2 * ty]);
+            const float2 ac = *reinterpret_cast<const float2*>(&As[kk][32 + 2 * ty]);
+            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
+            const float av[4] = {az.x, az.y, ac.x, ac.y};
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: conditioning (hoisted in_x + rank-1 upsampler), gate, highway
+    const float* condb = a.cond + (size_t)b * a.Tf * g.N;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int o = o0 + 2 * ty + r;
+        if (o >= H) continue;
+        const float bz = P[a.y.bd + (size_t)l * H2 + o], bc = P[a.y.bd + (size_t)l * H2 + H + o];
+        const float bxz = P[a.y.bx + (size_t)l * H2 + o], bxc = P[a.y.bx + (size_t)l * H2 + H + o];
+        float hv[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 4 * tx + j;
+            hv[j] = 0.f;
+            if (t >= a.Tp) continue;
+            float gz = bxz, gc = bxc;
+            for (int s = 0; s < seg; ++s) {
+                const int tt = t + s + a.coff;
+                int f = tt / g.U; const int jj = tt - f * g.U;
+                f = f < a.Tf ? f : a.Tf - 1;
+                const float w = P[a.y.wup + jj];
+                const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+                gz = fmaf(w, cr[o], gz);
+                gc = fmaf(w, cr[H + o], gc);
+            }
+            if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
+                int idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q;
+                idx = idx < 0 ? idx + g.Q : idx;
+                const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
+                gz += wa[o]; gc += wa[H + o];
+            }
+            const float z = sigm(gz * (acc[r][j] + bz));
+            const float c = tanhf(gc * (acc[2 + r][j] + bc));
+            hv[j] = (1.f - z) * c + z * hprev[(size_t)o * a.Tp + t];
+        }
+        float* dst = hnext + (size_t)o * a.Tp + t0 + 4 * tx;
+        if (t0 + 4 * tx + 3 < a.Tp && (a.Tp & 3) == 0) {
+            *reinterpret_cast<float4*>(dst) = make_float4(hv[0], hv[1], hv[2], hv[3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (t0 + 4 * tx + j < a.Tp) dst[j] = hv[j];
+        }
+    }
+}
+
+// ---- Y[b][m][t] = act(sum_k W[m][k] X[b][k][t] + bias[m]) : 64x64 tile, BK=16, 4x4 per thread -----
+__global__ __launch_bounds__(256) void gemm_wx_kernel(const float* __restrict__ W, int ldw,
+                                                      const float* __restrict__ bias,
+                                                      const float* __restrict__ X, size_t xstride_b,
+                                                      float* __restrict__ Y, size_t ystride_b,
+                                                      int M, int Kd, int T, int relu) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int b = blockIdx.z;
+    const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int tid = threadIdx.x;
+    const int tx = tid & 15, ty = tid >> 4;
+    const float* Xb = X + (size_t)b * xstride_b;
+    float* Yb = Y + (size_t)b * ystride_b;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < Kd; k0 += 16) {
+        {
+            const int rr = tid >> 2, kq = (tid & 3) * 4;
+            const int m = m0 + rr;
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (m < M) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (k0 + kq + e < Kd) v[e] = W[(size_t)m * ldw + k0 + kq + e];
+            }
+            As[kq + 0][rr] = v[0]; As[kq + 1][rr] = v[1]; As[kq + 2][rr] = v[2]; As[kq + 3][rr] = v[3];
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, tt = e & 63;
+            Bs[kk][tt] = (k0 + kk < Kd && t0 + tt < T) ? Xb[(size_t)(k0 + kk) * T + t0 + tt] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float4 aa = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
+            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
+            const float av[4] = {aa.x, aa.y, aa.z, aa.w};
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * ty + r;
+        if (m >= M) continue;
+        const float bv = bias[m];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 4 * tx + j;
+            if (t < T) {
+                const float v = acc[r][j] + bv;
+                Yb[(size_t)m * T + t] = relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+    }
+}
+
+size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+}  // namespace
+
 extern "C" int swn_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return SWN_E_NODEVICE;
     return n;
+}
+
+// work = hidden states (only when the caller does not pass hs) + skip activations + out_1 activations
+extern "C" size_t swn_forward_work_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    const long T = (long)n_frames * g.U;
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
+    if (Tp < 1) return 0;
+    return r64((size_t)batch * (g.L + 1) * g.H * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * g.O1 * Tp);
+}
+
+extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const float* cond, const void* audio,
+                           int batch, int n_frames, float* work, float* out, float* hs, void* stream_) {
+    FwdArgs a;
+    int rc = swn_make_geom(d, &a.g);
+    if (rc < 0) return rc;
+    const SwnGeom& g = a.g;
+    if (!packed || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+    swn_make_layout(&a.g, &a.y);
+    const long T = (long)n_frames * g.U;
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
+    if (Tp < 1) return SWN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream_;
+    const size_t hs_floats = r64((size_t)batch * (g.L + 1) * g.H * Tp);
+    float* hbuf = hs ? hs : work;
+    float* skipb = work + hs_floats;
+    float* o1b = skipb + r64((size_t)batch * g.S * Tp);
+    a.P = packed; a.cond = cond; a.audio = audio; a.hs = hbuf; a.B = batch; a.Tf = n_frames; a.Tp = (int)Tp;
+    a.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    const int tb64 = (int)((Tp + 63) / 64);
+    {
+        dim3 grid((unsigned)((Tp + 255) / 256), g.H < 16 ? g.H : 16, batch);
+        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a);
+    }
+    for (int l = 0; l < g.L; ++l) {
+        dim3 grid(tb64, (g.H + 31) / 32, batch);
+        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a, l);
+        else hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a, l);
+    }
+    const size_t hstride = (size_t)(g.L + 1) * g.H * Tp;
+    // skip: one GEMM over the L concatenated hidden states (requires Hp == H, i.e. H % 4 == 0)
+    if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
+    hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.S + 63) / 64, batch), dim3(256), 0, st,
+                       packed + a.y.wsk, g.L * g.Hp, packed + a.y.bsk, hbuf + (size_t)g.H * Tp, hstride,
+                       skipb, (size_t)g.S * Tp, g.S, g.L * g.H, (int)Tp, 1);
+    hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.O1 + 63) / 64, batch), dim3(256), 0, st,
+                       packed + a.y.w1, g.Sp, packed + a.y.b1, skipb, (size_t)g.S * Tp,
+                       o1b, (size_t)g.O1 * Tp, g.O1, g.S, (int)Tp, 1);
+    hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.NO + 63) / 64, batch), dim3(256), 0, st,
+                       packed + a.y.w2, g.O1p, packed + a.y.b2, o1b, (size_t)g.O1 * Tp,
+                       out, (size_t)g.NO * Tp, g.NO, g.O1, (int)Tp, 0);
+    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
 }

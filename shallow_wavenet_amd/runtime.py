@@ -136,7 +136,7 @@ class HipNet:
         d = ctypes.byref(self.desc)
         work = torch.empty(L.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
         out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
-        hs = torch.empty((cfg.L + 1, B, cfg.H, Tp), dtype=torch.float32, device=self.device) if want_hidden else None
+        hs = torch.empty((B, cfg.L + 1, cfg.H, Tp), dtype=torch.float32, device=self.device) if want_hidden else None
         with torch.cuda.device(self.device):
             _lib.check(L.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
                                      _ptr(out), _ptr(hs), _stream_ptr(self.device)), "forward")
