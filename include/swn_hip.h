@@ -125,6 +125,17 @@ int    swn_forward(const swn_net_desc* d, const float* packed_dev, const float* 
                    const void* audio_dev, int batch, int n_frames, float* work_dev,
                    float* out_dev, float* hs_dev, void* stream);
 
+/* ---- Laplace output split  (cswnv_shift1.py:228-267) -----------------------------------
+ * raw (B, n_out, Tp) from swn_forward  ->  time-major tensors the reference returns:
+ *   mu (B,Tp,seg) ; logb = logsigmoid(.) (B,Tp,seg) ; b = exp(logb) ; a (B,Tp,lpc) (NULL if lpc==0)
+ *   b_clip / logb_clip (optional, may be NULL): logb floored at -14.1621 (b >= 7.07e-7), :233-236
+ *   below_floor: int32[1] set non-zero when any logb < floor (the reference's torch.min test);
+ *   the caller zeroes it before the call.                                                    */
+int    swn_laplace_head(const swn_net_desc* d, const float* out_dev, int batch, int tp,
+                        float* mu_dev, float* b_dev, float* logb_dev, float* a_dev,
+                        float* b_clip_dev, float* logb_clip_dev, int32_t* below_floor_dev,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -238,6 +238,28 @@ def gen_numerics():
         listing.append(repr(dict(name=nm, rf=m.receptive_field, padding=list(m.padding),
                                  n_params=sum(p.numel() for p in m.parameters()), keys=keys)))
     out["geometry"] = np.array(listing)
+    # default-construction / initialize() RNG order: per-parameter digests after torch.manual_seed(123)
+    for nm, cfg in [("tiny_lap_s2l4", C.tiny("laplace", 2, 4)), ("tiny_softmax_wav", C.tiny("softmax", wav_conv_flag=True))]:
+        mod = ref_d.DSWNV if cfg.kind == "softmax" else ref_c.CSWNV
+        torch.manual_seed(123)
+        m = mod(**cfg.ctor_kwargs())
+        out[f"init_default_{nm}"] = np.stack([digest(v.numpy())[:3] for v in m.state_dict().values()])
+        m.apply(ref_d.initialize if cfg.kind == "softmax" else ref_c.initialize)
+        out[f"init_xavier_{nm}"] = np.stack([digest(v.numpy())[:3] for v in m.state_dict().values()])
+    # loss modules on fixed inputs
+    rng = np.random.Generator(np.random.PCG64(99))
+    mu = torch.from_numpy(rng.normal(size=(3, 50)).astype(np.float32))
+    b = torch.from_numpy(rng.uniform(1e-8, 0.5, size=(3, 50)).astype(np.float32))
+    tg = torch.from_numpy(rng.normal(size=(3, 50)).astype(np.float32))
+    out["loss_mu"], out["loss_b"], out["loss_t"] = mu.numpy(), b.numpy(), tg.numpy()
+    out["loss_nll"] = np.array([ref_c.LaplaceLoss()(mu, b, tg, log=False).item(),
+                                ref_c.LaplaceLoss()(mu, b, tg, clip=True, log=False).item(),
+                                ref_c.LaplaceLoss()(mu, b, tg, log_b=torch.log(b), clip=True, log=False).item()])
+    x = torch.from_numpy(rng.uniform(0.1, 2, size=(7, 33)).astype(np.float32))
+    y = torch.from_numpy(rng.uniform(0.1, 2, size=(7, 33)).astype(np.float32))
+    out["lsd_x"], out["lsd_y"] = x.numpy(), y.numpy()
+    out["lsd_vals"] = np.array([ref_c.LSDloss()(x, y).item(), ref_c.LSDloss()(x, y, L2=False).item(),
+                                ref_c.LSDloss()(x, y, LSD=False).item(), ref_c.LSDloss()(x, y, LSD=False, L2=False).item()])
     np.savez_compressed(os.path.join(GOLD, "g3_numerics.npz"), **out)
     print("[golden] g3_numerics")
 

@@ -59,6 +59,8 @@ SIGNATURES = {
     "swn_forward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
+    "swn_laplace_head": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 

@@ -224,6 +224,31 @@ __global__ __launch_bounds__(256) void gemm_wx_kernel(const float* __restrict__ 
 
 size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
+// raw (B, NO, Tp) -> time-major mu / b / logb / a (+ clipped copies); one thread per (b, t)
+__global__ __launch_bounds__(256) void laplace_head_kernel(const float* __restrict__ raw, int Tp, int seg, int lpc,
+                                                           float* mu, float* bsc, float* logb, float* acf,
+                                                           float* b_clip, float* logb_clip, int* below) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int b = blockIdx.y;
+    if (t >= Tp) return;
+    const int NO = 2 * seg + lpc;
+    const float* r = raw + (size_t)b * NO * Tp + t;
+    const float FLOOR = -14.162084148244246758816564788835f;
+    bool any = false;
+    for (int j = 0; j < seg; ++j) {
+        const size_t o = ((size_t)b * Tp + t) * seg + j;
+        mu[o] = r[(size_t)j * Tp];
+        const float y = r[(size_t)(seg + j) * Tp];
+        const float lb = fminf(y, 0.f) - log1pf(expf(-fabsf(y)));      // logsigmoid
+        logb[o] = lb;
+        bsc[o] = expf(lb);
+        any |= lb < FLOOR;
+        if (logb_clip) { const float lc = fmaxf(lb, FLOOR); logb_clip[o] = lc; b_clip[o] = expf(lc); }
+    }
+    for (int k = 0; k < lpc; ++k) acf[((size_t)b * Tp + t) * lpc + k] = r[(size_t)(2 * seg + k) * Tp];
+    if (any) atomicOr(below, 1);
+}
+
 }  // namespace
 
 extern "C" int swn_device_count(void) {
@@ -282,5 +307,19 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.NO + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.w2, g.O1p, packed + a.y.b2, o1b, (size_t)g.O1 * Tp,
                        out, (size_t)g.NO * Tp, g.NO, g.O1, (int)Tp, 0);
+    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+}
+
+extern "C" int swn_laplace_head(const swn_net_desc* d, const float* out, int batch, int tp, float* mu, float* b,
+                                float* logb, float* a, float* b_clip, float* logb_clip, int32_t* below,
+                                void* stream_) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    if (rc < 0) return rc;
+    if (g.kind != SWN_KIND_LAPLACE) return SWN_E_BADDESC;
+    if (!out || !mu || !b || !logb || !below || (g.lpc > 0 && !a) || batch < 1 || batch > 65535 || tp < 1 ||
+        ((b_clip == nullptr) != (logb_clip == nullptr)))
+        return SWN_E_BADARG;
+    hipLaunchKernelGGL(laplace_head_kernel, dim3((tp + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream_,
+                       out, tp, g.seg, g.lpc, mu, b, logb, a, b_clip, logb_clip, below);
     return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
 }

@@ -1,0 +1,113 @@
+"""Shared machinery of the two drop-in modules: parameter holders with the reference's
+state_dict names, and the cache that keeps a packed copy of the parameters in HBM.
+
+The holders carry parameters only; all arithmetic happens in the HIP kernels reached
+through `shallow_wavenet_amd.runtime.HipNet`.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import logging
+import time
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+from torch import nn
+
+from ..config import NetConfig
+from ..runtime import HipNet
+
+
+def initialize(m):
+    """Xavier-uniform Conv1d weights with zero bias, unit ConvTranspose weights with zero bias
+    (same effect as the reference helper, cswnv_shift1.py:20-34 / dswnv.py:50-64)."""
+    if isinstance(m, nn.Conv1d):
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0.0)
+    if isinstance(m, (nn.ConvTranspose2d, nn.ConvTranspose1d)):
+        nn.init.constant_(m.weight, 1.0)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0.0)
+
+
+class _Holder(nn.Module):
+    def forward(self, *a, **k):       # parameters only
+        raise RuntimeError("parameter holder: the computation runs in the fused HIP kernels")
+
+
+class UpSampling(_Holder):
+    """holds `conv` = ConvTranspose2d(1,1,(1,U),stride (1,U)) -> keys upsampling.conv.{weight,bias}"""
+
+    def __init__(self, upsampling_factor, bias=True):
+        super().__init__()
+        self.upsampling_factor = upsampling_factor
+        self.bias = bias
+        self.conv = nn.ConvTranspose2d(1, 1, kernel_size=(1, upsampling_factor),
+                                       stride=(1, upsampling_factor), bias=bias)
+
+
+class CausalConv1d(_Holder):
+    """holds `conv` = Conv1d(Cin, Cout, K, dilation=K**dil_fact); padding = K**(d+1) - K**d"""
+
+    def __init__(self, in_channels, out_channels, kernel_size, dil_fact=0, bias=True):
+        super().__init__()
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, kernel_size
+        self.dil_fact = dil_fact
+        self.dilation = kernel_size ** dil_fact
+        self.padding = kernel_size ** (dil_fact + 1) - self.dilation
+        self.bias = bias
+        self.conv = nn.Conv1d(in_channels, out_channels, kernel_size, padding=self.padding,
+                              dilation=self.dilation, bias=bias)
+
+
+class TwoSidedDilConv1d(_Holder):
+    """holds `conv` = ModuleList of the channel-expanding k=3 conditioning convs"""
+
+    def __init__(self, in_dim=39, kernel_size=3, layers=2):
+        super().__init__()
+        self.in_dim, self.kernel_size, self.layers = in_dim, kernel_size, layers
+        self.rec_field = kernel_size ** layers
+        self.conv = nn.ModuleList()
+        for i in range(layers):
+            self.conv.append(nn.Conv1d(in_dim * kernel_size ** i, in_dim * kernel_size ** (i + 1), kernel_size,
+                                       stride=1, dilation=kernel_size ** i,
+                                       padding=(kernel_size ** (i + 1) - kernel_size ** i) // 2))
+
+
+class EngineMixin:
+    """packed-parameter cache: rebuilt whenever a parameter tensor is replaced or modified in
+    place (load_state_dict, optimizer step, .to()/.cuda()); SURVEY.md 8b 'Checkpoint / ownership'."""
+
+    _cfg: NetConfig
+
+    def _engine_key(self):
+        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+
+    def _engine(self) -> HipNet:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError(
+                f"{type(self).__name__}: parameters are on {dev}; the MI355X build has no CPU path - "
+                "call model.cuda() on a machine with a HIP device")
+        key = self._engine_key()
+        cache = self.__dict__.get("_engine_cache")
+        if cache is None or cache[0] != key:
+            net = HipNet.from_state_dict(self._cfg, {k: v for k, v in self.state_dict().items()}, dev)
+            self.__dict__["_engine_cache"] = (key, net)
+            return net
+        return cache[1]
+
+    def set_packed_engine(self, net: HipNet) -> None:
+        """install an engine whose packed buffer arrived by RCCL broadcast (dist.py)."""
+        self.__dict__["_engine_cache"] = (self._engine_key(), net)
+
+
+def log_decode_speed(seg: int, n_steps: int, n_utts: int, seconds: float) -> None:
+    """the two summary lines of the reference loop (cswnv_shift1.py:417-422 / dswnv.py:386-391);
+    per-step times are not observable from inside one persistent launch, so the mean is used."""
+    n = max(n_steps * seg, 1)
+    per = seconds / n
+    logging.info("average time / sample = %.6f sec (%ld samples) [%.3f kHz/s]" % (per, n, 1.0 / (1000 * per)))
+    logging.info("average throughput / sample = %.6f sec (%ld samples * %ld) [%.3f kHz/s]" % (
+        seconds / (n * n_utts), n, n_utts, n * n_utts / (1000 * seconds)))

@@ -141,3 +141,19 @@ class HipNet:
             _lib.check(L.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
                                      _ptr(out), _ptr(hs), _stream_ptr(self.device)), "forward")
         return out, hs
+
+    def laplace_head(self, raw: torch.Tensor, clip: bool = False):
+        """raw (B, n_out, Tp) -> (mu, b, logb, a, b_clip, logb_clip, below_floor) time-major."""
+        cfg, L = self.cfg, self.lib
+        B, NO, Tp = raw.shape
+        seg, lpc = cfg.seg, cfg.lpc
+        mk = lambda w: torch.empty((B, Tp, w), dtype=torch.float32, device=self.device)
+        mu, b, logb = mk(seg), mk(seg), mk(seg)
+        a = mk(lpc) if lpc > 0 else None
+        bc, lc = (mk(seg), mk(seg)) if clip else (None, None)
+        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_laplace_head(ctypes.byref(self.desc), _ptr(raw.contiguous()), B, Tp, _ptr(mu), _ptr(b),
+                                          _ptr(logb), _ptr(a), _ptr(bc), _ptr(lc), _ptr(flag),
+                                          _stream_ptr(self.device)), "laplace_head")
+        return mu, b, logb, a, bc, lc, flag

@@ -1,0 +1,154 @@
+"""GPU parity tests of the teacher-forced stack and of the drop-in module API against the
+oracle and the golden fixtures recorded from the reference.
+
+Tolerance: 1e-5 absolute on mu / b / log b / a / logits (north_star), hidden states 5e-6.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from oracle import cpu_ref
+from shallow_wavenet_amd.nets import cswnv_shift1 as mc
+from shallow_wavenet_amd.nets import dswnv as md
+from shallow_wavenet_amd.runtime import HipNet
+from shallow_wavenet_amd.synth import synth_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+LAP_FWD = [n for n in golden_names() if "_lap_" in n and "fwd_0" in load_golden(n)[1]]
+SMX_FWD = [n for n in golden_names() if "softmax" in n and "fwd_audio_idx" in load_golden(n)[1]]
+
+
+def _sd(cfg, d):
+    return synth_state_dict(cfg, seed=int(d["wseed"]), flavor=str(d["flavor"]))
+
+
+@pytest.mark.parametrize("name", LAP_FWD)
+def test_laplace_stack_hidden_states_and_raw_head(gpu_ok, name):
+    cfg, d = load_golden(name)
+    sd = _sd(cfg, d)
+    net, P = HipNet.from_state_dict(cfg, sd, "cuda:0"), cpu_ref.as_params(sd)
+    aux, audio = torch.from_numpy(d["aux"]), torch.from_numpy(d["fwd_audio"])
+    raw, hs = net.forward(aux, audio, want_hidden=True)
+    ref_raw, ref_hs = cpu_ref.laplace_stack(cfg, P, aux, audio)
+    hs = hs.cpu().numpy()
+    for l, h in enumerate(ref_hs):
+        assert np.abs(hs[:, l] - h.numpy()).max() <= 5e-6, (name, l)
+    assert np.abs(raw.cpu().numpy() - ref_raw.numpy()).max() <= TOL
+
+
+@pytest.mark.parametrize("name", LAP_FWD)
+def test_cswnv_module_forward_matches_reference(gpu_ok, name):
+    cfg, d = load_golden(name)
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(cfg, d).items()})
+    m.cuda().eval()
+    aux, audio = torch.from_numpy(d["aux"]).cuda(), torch.from_numpy(d["fwd_audio"]).cuda()
+    with torch.no_grad():
+        res = m(aux, audio)
+        resc = m(aux, audio, do=False, clip=True)
+    assert len(res) == (4 if cfg.lpc > 0 else 3) and len(resc) == int(d["fwd_clip_n"])
+    for i, r in enumerate(res):
+        ref = d[f"fwd_{i}"]
+        assert tuple(r.shape) == ref.shape, (name, i)
+        assert np.abs(r.cpu().numpy() - ref).max() <= TOL, (name, i)
+    assert np.abs(resc[0].cpu().numpy() - d["fwd_0"]).max() <= TOL
+    assert np.abs(resc[1].cpu().numpy() - d["fwd_1"]).max() <= TOL          # unclipped b
+    assert float(resc[3].min()) >= -14.1621 - 1e-4                           # floored log b
+
+
+@pytest.mark.parametrize("name", ["g0_tiny_lap_s1l0_trained", "g0_tiny_lap_s5l4_trained", "g0_tiny_lap_s2l4_xavier",
+                                  "g1_bl6_lap_s1l0_b3_trained", "g1_bl6_lap_s5l4_b1_trained"])
+def test_cswnv_module_generate_matches_reference(gpu_ok, name):
+    """the documented way to reproduce the reference's CPU decode: same torch.manual_seed."""
+    cfg, d = load_golden(name)
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(cfg, d).items()})
+    m.cuda().eval()
+    n_samples = [int(n) for n in d["n_samples"]]
+    torch.manual_seed(int(d["noise_seed"]))
+    out = m.batch_fast_generate(torch.zeros(len(n_samples), cfg.seg).cuda(), torch.from_numpy(d["aux"]).cuda(),
+                                n_samples, 4410)
+    assert len(out) == len(n_samples)
+    for b, n in enumerate(n_samples):
+        assert out[b].shape == (n,) and out[b].dtype == np.float32
+        assert np.abs(out[b] - d[f"samples_{b}"]).max() <= TOL, (name, b)
+    # cached engine is invalidated when parameters change
+    with torch.no_grad():
+        m.out_2.bias.add_(0.25)
+    torch.manual_seed(int(d["noise_seed"]))
+    out2 = m.batch_fast_generate(torch.zeros(len(n_samples), cfg.seg).cuda(), torch.from_numpy(d["aux"]).cuda(),
+                                 n_samples, 4410)
+    assert np.abs(out2[0] - out[0]).max() > 1e-3
+
+
+@pytest.mark.parametrize("name", SMX_FWD)
+def test_dswnv_module_forward_matches_reference(gpu_ok, name):
+    cfg, d = load_golden(name)
+    m = md.DSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(cfg, d).items()})
+    m.cuda().eval()
+    idx = torch.from_numpy(d["fwd_audio_idx"]).cuda()
+    oh = md.OneHot(idx, cfg.n_quantize).transpose(1, 2)
+    with torch.no_grad():
+        logits = m(oh, torch.from_numpy(d["aux"]).cuda()).cpu().numpy()
+        logits_idx = m(idx, torch.from_numpy(d["aux"]).cuda()).cpu().numpy()
+    assert np.array_equal(logits, logits_idx)
+    assert logits.shape == (idx.shape[0], idx.shape[1], cfg.n_quantize)
+    assert np.abs(logits[:, :64] - d["fwd_logits_head"]).max() <= 2e-5
+    assert np.abs(logits[:, -64:] - d["fwd_logits_tail"]).max() <= 2e-5
+    dig = d["fwd_logits_dig"]
+    assert abs(logits.astype(np.float64).sum() - dig[0]) <= 1e-5 * dig[1]
+
+
+@pytest.mark.parametrize("name", ["g0_tiny_softmax", "g0_tiny_softmax_wav", "g1_bl6_softmax_b3"])
+def test_dswnv_module_generate_bit_exact(gpu_ok, name):
+    cfg, d = load_golden(name)
+    m = md.DSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(cfg, d).items()})
+    m.cuda().eval()
+    n_samples = [int(n) for n in d["n_samples"]]
+    torch.manual_seed(int(d["noise_seed"]))
+    out = m.batch_fast_generate(torch.full((len(n_samples), 1), cfg.n_quantize // 2, dtype=torch.int64).cuda(),
+                                torch.from_numpy(d["aux"]).cuda(), n_samples, 4410)
+    for b, n in enumerate(n_samples):
+        assert out[b].dtype == np.int64 and out[b].shape == (n,)
+        assert np.array_equal(out[b], d[f"samples_{b}"]), (name, b)
+
+
+def test_full_size_decode_is_self_consistent_with_the_oracle(gpu_ok):
+    """BASELINE cfg2 at a size the free-running oracle cannot cover in seconds (Tf=120 -> 13 200
+    steps): feed the GPU's own samples through the ORACLE's teacher-forced stack and rebuild
+    every sample from the same noise - a size-independent property."""
+    from shallow_wavenet_amd import config as C
+    from shallow_wavenet_amd.synth import synth_aux
+    cfg = C.bl6_laplace(1, 0)
+    sd = synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True)
+    net, P = HipNet.from_state_dict(cfg, sd, "cuda:0"), cpu_ref.as_params(sd)
+    Tf = 120
+    n = Tf * cfg.U
+    aux = torch.from_numpy(synth_aux(cfg, 1, Tf))
+    g = torch.Generator().manual_seed(1)
+    noise = torch.empty(1, n, 1).uniform_(-0.4999, 0.5, generator=g)
+    out, _ = net.decode(aux, n, noise)
+    s = out.cpu()                                                   # (1, n)
+    rf = cfg.receptive_field
+    # oracle teacher-forced stack on [zeros(rf+1) | samples] with replicate-padded conditioning
+    with torch.no_grad():
+        x = cpu_ref.upsample(cfg, P, cpu_ref.frontend(cfg, P, aux))
+        x = torch.nn.functional.pad(x, (rf, 0), "replicate")[:, :, : rf + n]
+        audio = torch.cat((torch.zeros(1, 1, rf + 1), s[:, None, :-1]), 2)
+        h = torch.nn.functional.softsign(cpu_ref.causal_conv(cpu_ref._lift(cfg, P, audio), P["causal.conv.weight"],
+                                                             P["causal.conv.bias"], 1))
+        tot = None
+        for l in range(cfg.L):
+            sk, h = cpu_ref.gated_layer(cfg, P, l, x, h)
+            tot = sk if tot is None else tot + sk
+        o = cpu_ref.head(cfg, P, tot)[:, :, rf:]                      # (1, 2, n)
+        mu, b = o[:, 0], torch.exp(torch.nn.functional.logsigmoid(o[:, 1]))
+        e = noise[:, :, 0]
+        rebuilt = torch.clamp(mu - b * e.sign() * torch.log1p(-2 * e.abs()), -1, 1)
+    assert float((rebuilt - s).abs().max()) <= TOL
+    assert float(s.abs().max()) < 0.999 and float(s.std()) > 1e-3     # a live, unsaturated signal
