@@ -49,7 +49,16 @@ def algorithmic_bytes_per_position(cfg: C.NetConfig, batch: int) -> float:
     return 4 * w_step + 4 * w_inx / U + batch * (4 * cfg.A0 / U + state_rd + state_wr + 4)
 
 
-def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 30):
+def host_threads() -> int:
+    """cores this process may use (cgroup/affinity aware), capped at the GPU box's 16-core share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 20):
     """time the oracle's free-running decode (reference per-step op structure) on the host cores."""
     from oracle import cpu_ref                      # checker only: never on the measured GPU path
     P = cpu_ref.as_params(sd)
@@ -58,8 +67,8 @@ def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 30):
     g = torch.Generator().manual_seed(1)
     noise = cpu_ref.laplace_noise(cfg, n // cfg.seg, 1, generator=g)
     best = None
-    ncores = os.cpu_count() or 1
-    for threads in sorted({1, ncores}):
+    ncores = host_threads()
+    for threads in sorted({1, min(ncores, 8)}):
         torch.set_num_threads(threads)
         t0 = time.time()
         cpu_ref.laplace_generate(cfg, P, aux, [n], noise)

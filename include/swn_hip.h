@@ -61,6 +61,8 @@ typedef struct swn_net_desc {
 /* ---- introspection --------------------------------------------------------------- */
 int         swn_abi_version(void);
 const char* swn_strerror(int code);
+/* text of the last HIP runtime failure seen by an entry point on this thread ("" if none) */
+const char* swn_last_error_detail(void);
 /* number of HIP devices visible, or a negative SWN_E_* */
 int         swn_device_count(void);
 /* receptive field / number of state_dict tensors, as CSWNV.__init__ computes them

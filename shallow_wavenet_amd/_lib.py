@@ -45,6 +45,7 @@ def desc_from_cfg(cfg: NetConfig) -> NetDesc:
 SIGNATURES = {
     "swn_abi_version": (c_int, []),
     "swn_strerror": (c_char_p, [c_int]),
+    "swn_last_error_detail": (c_char_p, []),
     "swn_device_count": (c_int, []),
     "swn_receptive_field": (c_int, [POINTER(NetDesc)]),
     "swn_num_tensors": (c_int, [POINTER(NetDesc)]),
@@ -82,6 +83,10 @@ def lib() -> ctypes.CDLL:
             return _lib
         if not os.path.exists(LIB_PATH):
             build()
+        # torch ships its own libamdhip64; it must be in the process BEFORE our library so that both
+        # resolve to ONE HIP runtime (device pointers and streams come from torch).  Loading ours
+        # first binds /opt/rocm's copy, which then reports "no ROCm-capable device".
+        import torch  # noqa: F401
         try:
             l = ctypes.CDLL(LIB_PATH)
         except OSError as e:
@@ -99,4 +104,5 @@ def lib() -> ctypes.CDLL:
 def check(rc: int, what: str = "") -> None:
     if rc != 0:
         msg = lib().swn_strerror(rc).decode()
-        raise RuntimeError(f"swn_hip {what}: {msg} ({rc})")
+        detail = lib().swn_last_error_detail().decode()
+        raise RuntimeError(f"swn_hip {what}: {msg} ({rc}) {detail}")

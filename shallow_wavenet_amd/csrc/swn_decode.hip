@@ -296,7 +296,7 @@ int launch_generic(const DecArgs& a, size_t lds, hipStream_t st) {
         hipLaunchKernelGGL((decode_generic_kernel<SEGT, SWN_KIND_LAPLACE>), dim3(a.B), dim3(NT), lds, st, a);
     else
         hipLaunchKernelGGL((decode_generic_kernel<SEGT, SWN_KIND_SOFTMAX>), dim3(a.B), dim3(NT), lds, st, a);
-    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+    return swn_launch_status("swn_decode(generic)");
 }
 
 int ring_plan(const SwnGeom& g, int* off, int* len) {
@@ -331,6 +331,7 @@ extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const floa
         return SWN_E_BADARG;
     if ((long)n_steps * a.g.seg > (long)n_frames * a.g.U) return SWN_E_BADARG;   // conditioning too short
     hipStream_t st = (hipStream_t)stream_;
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls
     if (n_steps == 0) return SWN_OK;
     if (variant == 0 || variant == 2) {
         rc = swn_decode_bl6_try(d, packed, cond, batch, n_frames, n_steps, noise, forced, out, heads, stream_);

@@ -540,7 +540,7 @@ int launch(const B6Args& a, hipStream_t st) {
             return SWN_E_LAUNCH;
     }
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(NT), T::lds_bytes, st, a);
-    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+    return swn_launch_status("swn_decode(bl6)");
 }
 
 }  // namespace
@@ -556,6 +556,7 @@ extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, co
     a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.out = out; a.heads = heads;
     a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.U = g.U; a.N = g.N;
     hipStream_t st = (hipStream_t)stream_;
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported
     if (g.kind == SWN_KIND_LAPLACE && g.S == 128) {
         if (g.seg == 1 && g.lpc == 0) return launch<Tr<128, 1, 0, SWN_KIND_LAPLACE, 0>>(a, st);
         if (g.seg == 1 && g.lpc == 4) return launch<Tr<128, 1, 4, SWN_KIND_LAPLACE, 0>>(a, st);

@@ -123,6 +123,7 @@ extern "C" int swn_frontend(const swn_net_desc* d, const float* packed, const fl
     if (!packed || !aux || !work || !cond || batch < 1 || n_frames < 1 || batch > 65535) return SWN_E_BADARG;
     SwnLayout y; swn_make_layout(&g, &y);
     hipStream_t st = (hipStream_t)stream_;
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported
     const size_t bt = (size_t)batch * n_frames;
     // scale_in
     float* cur = work;
@@ -145,5 +146,5 @@ extern "C" int swn_frontend(const swn_net_desc* d, const float* packed, const fl
         hipLaunchKernelGGL(cond_gemm_kernel, grid, dim3(256), 0, st, src, packed + y.wx, cond,
                            n_frames, g.N, g.A0, g.A0p);
     }
-    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+    return swn_launch_status("swn_frontend");
 }

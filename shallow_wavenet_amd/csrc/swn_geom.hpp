@@ -151,3 +151,14 @@ static inline __host__ void swn_make_layout(const SwnGeom* g, SwnLayout* y) {
 static inline __host__ int swn_tensor_count(const SwnGeom* g) {
     return 2 + 2 * g->auxl + 2 + (g->wav ? 2 : 0) + 2 + 6 * g->L + 4;
 }
+
+// thread-local text of the last HIP failure seen by an entry point (swn_last_error_detail())
+extern "C" void swn_set_error_detail(const char* where, const char* what);
+#ifdef HIP_INCLUDE_HIP_HIP_RUNTIME_H
+static inline int swn_launch_status(const char* where) {
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return SWN_OK;
+    swn_set_error_detail(where, hipGetErrorString(e));
+    return SWN_E_LAUNCH;
+}
+#endif

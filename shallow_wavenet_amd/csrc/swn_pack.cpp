@@ -3,11 +3,18 @@
 //  decode_cswnv_laplace-shift1.py:223-224 as the thing that reaches the GPU; the packed
 //  buffer is uploaded once and broadcast over RCCL.)
 #include <math.h>
+#include <stdio.h>
 #include <string.h>
 #include <vector>
 #include "swn_geom.hpp"
 
 extern "C" int swn_abi_version(void) { return SWN_ABI_VERSION; }
+
+static thread_local char g_detail[256] = "";
+extern "C" void swn_set_error_detail(const char* where, const char* what) {
+    snprintf(g_detail, sizeof(g_detail), "%s: %s", where ? where : "?", what ? what : "?");
+}
+extern "C" const char* swn_last_error_detail(void) { return g_detail; }
 
 extern "C" const char* swn_strerror(int code) {
     switch (code) {

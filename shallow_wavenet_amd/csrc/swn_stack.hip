@@ -278,6 +278,7 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     if (Tp < 1) return SWN_E_BADARG;
     hipStream_t st = (hipStream_t)stream_;
+    (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported
     const size_t hs_floats = r64((size_t)batch * (g.L + 1) * g.H * Tp);
     float* hbuf = hs ? hs : work;
     float* skipb = work + hs_floats;
@@ -307,7 +308,7 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.NO + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.w2, g.O1p, packed + a.y.b2, o1b, (size_t)g.O1 * Tp,
                        out, (size_t)g.NO * Tp, g.NO, g.O1, (int)Tp, 0);
-    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+    return swn_launch_status("swn_forward");
 }
 
 extern "C" int swn_laplace_head(const swn_net_desc* d, const float* out, int batch, int tp, float* mu, float* b,
@@ -319,7 +320,8 @@ extern "C" int swn_laplace_head(const swn_net_desc* d, const float* out, int bat
     if (!out || !mu || !b || !logb || !below || (g.lpc > 0 && !a) || batch < 1 || batch > 65535 || tp < 1 ||
         ((b_clip == nullptr) != (logb_clip == nullptr)))
         return SWN_E_BADARG;
+    (void)hipGetLastError();
     hipLaunchKernelGGL(laplace_head_kernel, dim3((tp + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream_,
                        out, tp, g.seg, g.lpc, mu, b, logb, a, b_clip, logb_clip, below);
-    return hipGetLastError() == hipSuccess ? SWN_OK : SWN_E_LAUNCH;
+    return swn_launch_status("swn_forward");
 }
