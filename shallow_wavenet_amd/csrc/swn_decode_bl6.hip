@@ -70,7 +70,8 @@ struct Tr {
     static constexpr int o_tnz = o_hist + r4(WN);         // [2][8] Laplace deviates of the next step
     static constexpr int o_cz = o_tnz + 16;               // cb[64], cv[2][64], cc[2][64]
     static constexpr int o_w2 = o_cz + 5 * H;             // laplace: out_2 rows [NO][S] (+b2)
-    static constexpr int o_wl = o_w2 + (KIND_ == SWN_KIND_LAPLACE ? NO * S_ + r4(NO) : 0);   // [L-NREG][8][512][4]
+    static constexpr int o_bias = o_w2 + (KIND_ == SWN_KIND_LAPLACE ? NO * S_ + r4(NO) : 0);   // bsk[S], b1[O1], (softmax) b2[NO]
+    static constexpr int o_wl = o_bias + S_ + O1 + (KIND_ == SWN_KIND_SOFTMAX ? NO : 0);          // [L-NREG][8][512][4]
     static constexpr int o_end = o_wl + (L - NREG) * 8 * NT * 4;
     static constexpr size_t lds_bytes = (size_t)o_end * sizeof(float);
 };
@@ -118,6 +119,17 @@ __device__ __forceinline__ float tanh_c(float x) {        // (1 - e^-2|x|) / (1 
 }
 __device__ __forceinline__ float ssign(float x) { return x * rcp_c(1.f + fabsf(x)); }
 
+// Workgroup barrier that orders LDS traffic only: the cross-wave hand-offs of this kernel all go
+// through LDS; a plain __syncthreads() also drains (vmcnt(0)) global loads that may stay in flight.
+__device__ __forceinline__ void lds_barrier() {
+#ifdef SWN_SYNC
+    __syncthreads(); return;
+#endif
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <int NP>
 __device__ __forceinline__ float pick(const float (&a)[NP], int p) {
     float v = a[0];
@@ -128,7 +140,7 @@ __device__ __forceinline__ float pick(const float (&a)[NP], int p) {
 
 // One DCRNN layer for NP consecutive positions q0..q0+NP-1 (cswnv_shift1.py:281-285).
 template <class T, int LAYER, int NP>
-__device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float (&w)[2][16], int q0,
+__device__ __forceinline__ void layer_phase(float* lds, const float (&w)[2][16], int q0,
                                             const float (&wj)[T::SEG], const int (&pb)[T::SEG]) {
     constexpr int dil = 1 << LAYER;
     constexpr int R = T::ring_len(LAYER);
@@ -137,6 +149,18 @@ __device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float
     float az[NP], ac[NP];
 #pragma unroll
     for (int j = 0; j < NP; ++j) { az[j] = 0.f; ac[j] = 0.f; }
+    // operands of the gate epilogue are fetched up front so their LDS latency hides under the FMAs
+    // (lanes 0/1 of an octet: gate / candidate row; other lanes read valid but unused words)
+    [[maybe_unused]] float e_bd = 0.f, e_gx = 0.f, e_hp = 0.f;
+    if constexpr (NP == 1) {
+        const int pr = p & 1;
+        e_bd = lds[T::o_bd + LAYER * 2 * H + pr * H + o];
+        e_gx = lds[T::o_bx + LAYER * 2 * H + pr * H + o];
+#pragma unroll
+        for (int s = 0; s < T::SEG; ++s)
+            e_gx = fmaf(wj[s], lds[T::o_gp + pb[s] + (LAYER * T::SEG + s) * 2 * H + pr * H + o], e_gx);
+        e_hp = ring[(q0 & (R - 1)) * H + o];
+    }
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
         // inputs 32m+4p..+3 of [tap0 = position q-dil | tap1 = position q]
@@ -164,6 +188,33 @@ __device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float
 #pragma unroll
     for (int j = 0; j < NP; ++j) { az[j] = sum8(az[j]); ac[j] = sum8(ac[j]); }
     __builtin_amdgcn_sched_barrier(0);              // keep the gate epilogue behind the reduction
+#ifndef SWN_NO_SPLIT
+    if constexpr (NP == 1) {
+        // one position: lane 0 evaluates the gate (sigmoid), lane 1 the candidate (tanh), concurrently
+        if (p < 2) {
+            const int q = q0;
+            const float sa = (p == 0 ? az[0] : ac[0]) + e_bd;
+            const float v = e_gx * sa;
+            float res;
+            if (fabsf(v) > 9.02f && p == 1) {
+                res = copysignf(1.f, v);                                       // tanh saturated in fp32
+            } else {
+                const float e = exp_c(p == 0 ? -v : -2.f * fabsf(v));
+                const float r = rcp_c(1.f + e);
+                res = p == 0 ? r : copysignf((1.f - e) * r, v);                // z | tanh
+            }
+            const float c = dpp_f<0xF5>(res);                                  // quad_perm [1,1,3,3]: lane 0 <- lane 1
+            if (p == 0) {
+                const float hn = (1.f - res) * c + res * e_hp;
+                if (LAYER + 1 < L) {
+                    constexpr int R2 = T::ring_len(LAYER + 1 < L ? LAYER + 1 : LAYER);
+                    lds[T::o_ring + T::ring_off(LAYER + 1 < L ? LAYER + 1 : LAYER) + (q & (R2 - 1)) * H + o] = hn;
+                }
+                lds[T::o_hcat + LAYER * H + o] = hn;
+            }
+        }
+    } else
+#endif
     if (p < NP) {                                   // lane p finishes position q0+p
         const int q = q0 + p;
         const float sz = pick<NP>(az, p) + lds[T::o_bd + LAYER * 2 * H + o];
@@ -191,7 +242,7 @@ __device__ __forceinline__ void layer_phase(float* __restrict__ lds, const float
 
 // out_skip slice of one layer, 4 lanes per row, weights streamed from the lane-tiled copy.
 template <class T, int LAYER>
-__device__ __forceinline__ void skip_slice(const float* __restrict__ lds, __amdgpu_buffer_rsrc_t wsk2,
+__device__ __forceinline__ void skip_slice(const float* lds, __amdgpu_buffer_rsrc_t wsk2,
                                            float (&sacc)[T::S / 128]) {
     constexpr int layer = LAYER;
     const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
@@ -208,9 +259,36 @@ __device__ __forceinline__ void skip_slice(const float* __restrict__ lds, __amdg
     }
 }
 
+// Software-pipelined form: the weights of slice LAYER are issued into registers one phase ahead and
+// stay in flight across the LDS-only barrier.
+template <class T, int LAYER>
+__device__ __forceinline__ void skip_issue(__amdgpu_buffer_rsrc_t wsk2, float4 (&wsl)[4 * (T::S / 128)]) {
+    const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
+#pragma unroll
+    for (int ps = 0; ps < T::S / 128; ++ps)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm)
+            wsl[ps * 4 + mm] = buf_ld4(wsk2, (unsigned)((hr + 128 * ps) * 4 + hp) * 16u,
+                                       (unsigned)((LAYER * 4 + mm) * T::S) * 64u);
+}
+template <class T, int LAYER>
+__device__ __forceinline__ void skip_consume(const float* lds, const float4 (&wsl)[4 * (T::S / 128)],
+                                             float (&sacc)[T::S / 128]) {
+    const int hp = threadIdx.x & 3;
+#pragma unroll
+    for (int ps = 0; ps < T::S / 128; ++ps)
+#pragma unroll
+        for (int mm = 0; mm < 4; ++mm) {
+            const float4 w = wsl[ps * 4 + mm];
+            const float4 x = *reinterpret_cast<const float4*>(lds + T::o_hcat + LAYER * H + 16 * mm + 4 * hp);
+            sacc[ps] = fmaf(w.x, x.x, sacc[ps]); sacc[ps] = fmaf(w.y, x.y, sacc[ps]);
+            sacc[ps] = fmaf(w.z, x.z, sacc[ps]); sacc[ps] = fmaf(w.w, x.w, sacc[ps]);
+        }
+}
+
 // rows x NI mat-vec, 4 lanes per row, lane-tiled weights [NI/16][rows][4][4] streamed from L2.
 template <int ROWS, int NI>
-__device__ __forceinline__ void tiled_matvec(__amdgpu_buffer_rsrc_t wt, const float* __restrict__ bias,
+__device__ __forceinline__ void tiled_matvec(__amdgpu_buffer_rsrc_t wt, const float* bias,
                                              const float* x, float* y, bool relu) {
     const int hr = threadIdx.x >> 2, hp = threadIdx.x & 3;
 #pragma unroll
@@ -249,6 +327,12 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     for (int e = tid; e < L * 2 * H; e += NT) { lds[T::o_bx + e] = P[a.y.bx + e]; lds[T::o_bd + e] = P[a.y.bd + e]; }
     for (int e = tid; e < U; e += NT) lds[T::o_wup + e] = P[a.y.wup + e];
     for (int e = tid; e < H; e += NT) lds[T::o_cz + e] = P[a.y.cb + e];
+    // head biases live in LDS: a global load consumed inside a phase would drain (in-order vmcnt) every
+    // weight load that is deliberately in flight
+    for (int e = tid; e < S; e += NT) lds[T::o_bias + e] = P[a.y.bsk + e];
+    for (int e = tid; e < T::O1; e += NT) lds[T::o_bias + S + e] = P[a.y.b1 + e];
+    if (KIND == SWN_KIND_SOFTMAX)
+        for (int e = tid; e < T::NO; e += NT) lds[T::o_bias + S + T::O1 + e] = P[a.y.b2 + e];
     if (KIND == SWN_KIND_LAPLACE) {
         for (int e = tid; e < 2 * H; e += NT) { lds[T::o_cz + H + e] = P[a.y.cv + e]; lds[T::o_cz + 3 * H + e] = P[a.y.cc + e]; }
         for (int e = tid; e < T::NO * S; e += NT) lds[T::o_w2 + e] = P[a.y.w2 + (size_t)(e / S) * r4(S) + (e % S)];
@@ -292,7 +376,9 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     const int n_pro = RF - SEG + 1;
 
     // conditioning taps of the position this lane finishes: upsampler weight and frame buffer offset
-    auto cond_taps = [&](int q0, float (&wj)[SEG], int (&pb)[SEG]) {
+    // `single`: one position per pass (prologue, or seg == 1): every lane takes the taps of q0 itself,
+    // because the split gate epilogue runs on lanes 0 AND 1 of an octet for that one position.
+    auto cond_taps = [&](int q0, float (&wj)[SEG], int (&pb)[SEG], bool single) {
         const int t0 = q0 - RF;
         const int tlo = t0 < 0 ? 0 : t0;
         if (tlo >= tb + U) {                  // step crossed into the next frame: refill the free buffer
@@ -301,7 +387,7 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
         }
 #pragma unroll
         for (int s = 0; s < SEG; ++s) {
-            int tt = t0 + p + s; tt = tt < 0 ? 0 : tt;
+            int tt = t0 + (single ? 0 : p) + s; tt = tt < 0 ? 0 : tt;
             int rel = tt - tb;
             int fsel = fb;
             if (rel >= U) { rel -= U; fsel = fb + 1; }
@@ -364,28 +450,35 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     };
     // Laplace deviate of the uniform draw, -> LDS slot of step `step` (computed by wave 1, off the
     // critical path): tn = sign(e) * log1p(-2|e|)   (cswnv_shift1.py:374-376)
+    // The raw draw is fetched one call earlier still (e_next), so its HBM/L2 latency is never waited on.
+    float e_next = 0.f;
     auto noise_ahead = [&](int step) {
-        if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG && step < a.n_steps) {
+        if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG) {
             const int j = tid - 64;
-            const float e = a.noise[((size_t)b * a.n_steps + step) * SEG + j];
-            const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
-            lds[T::o_tnz + (step & 1) * 8 + j] = sg * log1pf(-2.f * fabsf(e));
+            if (step < a.n_steps) {
+                const float e = e_next;
+                const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+                lds[T::o_tnz + (step & 1) * 8 + j] = sg * log1pf(-2.f * fabsf(e));
+            }
+            if (step + 1 < a.n_steps) e_next = a.noise[((size_t)b * a.n_steps + step + 1) * SEG + j];
         }
     };
+    if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG && a.n_steps > 0)
+        e_next = a.noise[(size_t)b * a.n_steps * SEG + (tid - 64)];
 
     // ---- prologue: seed positions 0..rf-seg, one position per pass (cswnv_shift1.py:321-334)
 #pragma unroll 1
     for (int q = 0; q < n_pro; ++q) {
         float wj[SEG]; int pb[SEG];
-        cond_taps(q, wj, pb);
+        cond_taps(q, wj, pb, true);
         input_seed(q);
-        __syncthreads();
-        layer_phase<T, 0, 1>(lds, wreg[0], q, wj, pb); __syncthreads();
-        layer_phase<T, 1, 1>(lds, wreg[1], q, wj, pb); __syncthreads();
-        layer_phase<T, 2, 1>(lds, wreg[2], q, wj, pb); __syncthreads();
-        layer_phase<T, 3, 1>(lds, wreg[3], q, wj, pb); __syncthreads();
-        layer_phase<T, 4, 1>(lds, wreg[4], q, wj, pb); __syncthreads();
-        layer_phase<T, 5, 1>(lds, wreg[5], q, wj, pb); __syncthreads();
+        lds_barrier();
+        layer_phase<T, 0, 1>(lds, wreg[0], q, wj, pb); lds_barrier();
+        layer_phase<T, 1, 1>(lds, wreg[1], q, wj, pb); lds_barrier();
+        layer_phase<T, 2, 1>(lds, wreg[2], q, wj, pb); lds_barrier();
+        layer_phase<T, 3, 1>(lds, wreg[3], q, wj, pb); lds_barrier();
+        layer_phase<T, 4, 1>(lds, wreg[4], q, wj, pb); lds_barrier();
+        layer_phase<T, 5, 1>(lds, wreg[5], q, wj, pb); lds_barrier();
     }
 
     // ---- generation (cswnv_shift1.py:348-402 / dswnv.py:338-374)
@@ -410,32 +503,78 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
 #ifdef SWN_STAMP
         tprev = __builtin_amdgcn_s_memtime();
 #endif
-        cond_taps(q0, wj, pb);
+        cond_taps(q0, wj, pb, SEG == 1);
         float sacc[S / 128];
 #pragma unroll
         for (int ps = 0; ps < S / 128; ++ps) sacc[ps] = 0.f;
-        __syncthreads(); STAMP(0)
-        layer_phase<T, 0, SEG>(lds, wreg[0], q0, wj, pb); __syncthreads(); STAMP(1)
-        layer_phase<T, 1, SEG>(lds, wreg[1], q0, wj, pb); skip_slice<T, 0>(lds, wsk2, sacc); __syncthreads(); STAMP(2)
-        layer_phase<T, 2, SEG>(lds, wreg[2], q0, wj, pb); skip_slice<T, 1>(lds, wsk2, sacc); __syncthreads(); STAMP(3)
-        layer_phase<T, 3, SEG>(lds, wreg[3], q0, wj, pb); skip_slice<T, 2>(lds, wsk2, sacc); __syncthreads(); STAMP(4)
-        layer_phase<T, 4, SEG>(lds, wreg[4], q0, wj, pb); skip_slice<T, 3>(lds, wsk2, sacc); __syncthreads(); STAMP(5)
-        layer_phase<T, 5, SEG>(lds, wreg[5], q0, wj, pb); skip_slice<T, 4>(lds, wsk2, sacc); __syncthreads(); STAMP(6)
-        skip_slice<T, 5>(lds, wsk2, sacc);
+        [[maybe_unused]] float4 w1p[8];
+        lds_barrier(); STAMP(0)
+#ifdef SWN_NO_PREF
+        if constexpr (false) {
+#else
+        if constexpr (S == 128 && SEG <= 2) {
+#endif
+            // out_skip weights are issued one phase ahead and stay in flight across the LDS-only barrier
+            float4 wsl[4];
+            layer_phase<T, 0, SEG>(lds, wreg[0], q0, wj, pb); skip_issue<T, 0>(wsk2, wsl); lds_barrier(); STAMP(1)
+            layer_phase<T, 1, SEG>(lds, wreg[1], q0, wj, pb); skip_consume<T, 0>(lds, wsl, sacc); skip_issue<T, 1>(wsk2, wsl); lds_barrier(); STAMP(2)
+            layer_phase<T, 2, SEG>(lds, wreg[2], q0, wj, pb); skip_consume<T, 1>(lds, wsl, sacc); skip_issue<T, 2>(wsk2, wsl); lds_barrier(); STAMP(3)
+            layer_phase<T, 3, SEG>(lds, wreg[3], q0, wj, pb); skip_consume<T, 2>(lds, wsl, sacc); skip_issue<T, 3>(wsk2, wsl); lds_barrier(); STAMP(4)
+            layer_phase<T, 4, SEG>(lds, wreg[4], q0, wj, pb); skip_consume<T, 3>(lds, wsl, sacc); skip_issue<T, 4>(wsk2, wsl); lds_barrier(); STAMP(5)
+            layer_phase<T, 5, SEG>(lds, wreg[5], q0, wj, pb); skip_consume<T, 4>(lds, wsl, sacc); skip_issue<T, 5>(wsk2, wsl); lds_barrier(); STAMP(6)
+            skip_consume<T, 5>(lds, wsl, sacc);
+#ifdef SWN_W1PREF
+            // out_1 weights: issued now, they fly during the reduction and the barrier
+            {
+                const int hr = tid >> 2, hp = tid & 3;
+#pragma unroll
+                for (int mm = 0; mm < 8; ++mm)
+                    w1p[mm] = buf_ld4(w12, (unsigned)(hr * 4 + hp) * 16u, (unsigned)(mm * T::O1) * 64u);
+            }
+#endif
+        } else {
+            layer_phase<T, 0, SEG>(lds, wreg[0], q0, wj, pb); lds_barrier(); STAMP(1)
+            layer_phase<T, 1, SEG>(lds, wreg[1], q0, wj, pb); skip_slice<T, 0>(lds, wsk2, sacc); lds_barrier(); STAMP(2)
+            layer_phase<T, 2, SEG>(lds, wreg[2], q0, wj, pb); skip_slice<T, 1>(lds, wsk2, sacc); lds_barrier(); STAMP(3)
+            layer_phase<T, 3, SEG>(lds, wreg[3], q0, wj, pb); skip_slice<T, 2>(lds, wsk2, sacc); lds_barrier(); STAMP(4)
+            layer_phase<T, 4, SEG>(lds, wreg[4], q0, wj, pb); skip_slice<T, 3>(lds, wsk2, sacc); lds_barrier(); STAMP(5)
+            layer_phase<T, 5, SEG>(lds, wreg[5], q0, wj, pb); skip_slice<T, 4>(lds, wsk2, sacc); lds_barrier(); STAMP(6)
+            skip_slice<T, 5>(lds, wsk2, sacc);
+        }
         {
             const int hr = tid >> 2, hp = tid & 3;
 #pragma unroll
             for (int ps = 0; ps < S / 128; ++ps) {
                 const float v = sum4(sacc[ps]);
-                if (hp == 0) lds[T::o_skip + hr + 128 * ps] = fmaxf(v + P[a.y.bsk + hr + 128 * ps], 0.f);
+                if (hp == 0) lds[T::o_skip + hr + 128 * ps] = fmaxf(v + lds[T::o_bias + hr + 128 * ps], 0.f);
             }
         }
-        __syncthreads(); STAMP(7)
+        lds_barrier(); STAMP(7)
         // wave 1 prepares the next step's Laplace deviates while the out_1 weights are in flight; wave 0
         // left the previous tail long ago, so the slot it overwrites ((i+1)&1 == (i-1)&1) is free
         noise_ahead(i + 1);
-        tiled_matvec<T::O1, S>(w12, P + a.y.b1, lds + T::o_skip, lds + T::o_o1, true);
-        __syncthreads(); STAMP(8)
+#ifndef SWN_W1PREF
+        if constexpr (false) {
+#else
+        if constexpr (S == 128 && SEG <= 2) {
+#endif
+            const int hr = tid >> 2, hp = tid & 3;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int mm = 0; mm < 8; mm += 2) {
+                const float4 x0 = *reinterpret_cast<const float4*>(lds + T::o_skip + 16 * mm + 4 * hp);
+                const float4 x1 = *reinterpret_cast<const float4*>(lds + T::o_skip + 16 * (mm + 1) + 4 * hp);
+                a0 = fmaf(w1p[mm].x, x0.x, a0); a0 = fmaf(w1p[mm].y, x0.y, a0);
+                a0 = fmaf(w1p[mm].z, x0.z, a0); a0 = fmaf(w1p[mm].w, x0.w, a0);
+                a1 = fmaf(w1p[mm + 1].x, x1.x, a1); a1 = fmaf(w1p[mm + 1].y, x1.y, a1);
+                a1 = fmaf(w1p[mm + 1].z, x1.z, a1); a1 = fmaf(w1p[mm + 1].w, x1.w, a1);
+            }
+            const float v = sum4(a0 + a1);
+            if (hp == 0) lds[T::o_o1 + hr] = fmaxf(v + lds[T::o_bias + S + hr], 0.f);
+        } else {
+            tiled_matvec<T::O1, S>(w12, lds + T::o_bias + S, lds + T::o_skip, lds + T::o_o1, true);
+        }
+        lds_barrier(); STAMP(8)
 
         if (KIND == SWN_KIND_LAPLACE) {
             if (tid < 64) {
@@ -485,8 +624,8 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                 }
             }
         } else {
-            tiled_matvec<T::NO, T::O1>(w22, P + a.y.b2, lds + T::o_o1, lds + T::o_o2, false);
-            __syncthreads();
+            tiled_matvec<T::NO, T::O1>(w22, lds + T::o_bias + S + T::O1, lds + T::o_o1, lds + T::o_o2, false);
+            lds_barrier();
             if (HEADS_ON && a.heads)
                 for (int e = tid; e < T::NO; e += NT) a.heads[((size_t)b * a.n_steps + i) * T::NO + e] = lds[T::o_o2 + e];
             if (tid < 64) {
