@@ -12,6 +12,14 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# the GPU box exposes every host core to os.cpu_count() but grants ~16: an oversubscribed
+# torch thread pool makes the CPU oracle crawl
+try:
+    import torch as _torch
+    _torch.set_num_threads(max(1, min(8, len(os.sched_getaffinity(0)))))
+except Exception:  # pragma: no cover
+    pass
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
