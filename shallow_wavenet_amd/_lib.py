@@ -60,6 +60,11 @@ SIGNATURES = {
     "swn_forward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
                             c_void_p, c_void_p, c_void_p]),
+    "swn_bf16_weight_bytes": (c_size_t, [POINTER(NetDesc)]),
+    "swn_pack_bf16": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p]),
+    "swn_forward_bf16_work_bytes": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
+    "swn_forward_bf16": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
     "swn_laplace_head": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

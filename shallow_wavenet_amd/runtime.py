@@ -142,6 +142,31 @@ class HipNet:
                                      _ptr(out), _ptr(hs), _stream_ptr(self.device)), "forward")
         return out, hs
 
+    def forward_bf16(self, aux: torch.Tensor, audio: torch.Tensor, cond: Optional[torch.Tensor] = None):
+        """bf16 MFMA variant of `forward` (BL6-class Laplace nets): raw (B, n_out, Tp) fp32."""
+        cfg, L = self.cfg, self.lib
+        d = ctypes.byref(self.desc)
+        nbytes = L.swn_bf16_weight_bytes(d)
+        if nbytes == 0:
+            raise RuntimeError("bf16 stack kernels are built for the BL6-class Laplace geometry only")
+        if cond is None:
+            cond = self.frontend(aux)
+        B, Tf = cond.shape[0], cond.shape[1]
+        if getattr(self, "_wbf16", None) is None:
+            self._wbf16 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            with torch.cuda.device(self.device):
+                _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _stream_ptr(self.device)), "pack_bf16")
+        Tp = Tf * cfg.U - 2 * cfg.seg + 1
+        audio = audio.to(self.device, torch.float32).contiguous()
+        if audio.numel() != B * (Tf * cfg.U - cfg.seg):
+            raise RuntimeError("audio has the wrong size")
+        work = torch.empty(L.swn_forward_bf16_work_bytes(d, B, Tf), dtype=torch.uint8, device=self.device)
+        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
+                                          _ptr(work), _ptr(out), _stream_ptr(self.device)), "forward_bf16")
+        return out
+
     def laplace_head(self, raw: torch.Tensor, clip: bool = False):
         """raw (B, n_out, Tp) -> (mu, b, logb, a, b_clip, logb_clip, below_floor) time-major."""
         cfg, L = self.cfg, self.lib

@@ -1,0 +1,49 @@
+"""GPU: bf16 MFMA teacher-forced stack (training-speed path, BL6 class) against the oracle.
+bf16 has 8 mantissa bits: tolerance 3e-3 absolute on raw head outputs of magnitude ~5 (observed
+7e-4 max, 7e-5 mean); the fp32 kernels keep the 1e-5 parity bar (test_gpu_forward_parity.py)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cpu_ref
+from shallow_wavenet_amd import config as C
+from shallow_wavenet_amd.runtime import HipNet
+from shallow_wavenet_amd.synth import synth_aux, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["g1_bl6_lap_s1l0_b1_trained", "g1_bl6_lap_s1l0_b1_xavier", "g1_bl6_lap_s5l4_b1_trained"])
+def test_bf16_stack_tracks_the_oracle(gpu_ok, name):
+    cfg, d = load_golden(name)
+    sd = synth_state_dict(cfg, seed=int(d["wseed"]), flavor=str(d["flavor"]))
+    net, P = HipNet.from_state_dict(cfg, sd, "cuda:0"), cpu_ref.as_params(sd)
+    aux, audio = torch.from_numpy(d["aux"]), torch.from_numpy(d["fwd_audio"])
+    raw = net.forward_bf16(aux, audio).cpu().numpy()
+    ref, _ = cpu_ref.laplace_stack(cfg, P, aux, audio)
+    ref = ref.numpy()
+    assert raw.shape == ref.shape
+    err = np.abs(raw - ref)
+    assert err.max() <= 3e-3 * max(1.0, np.abs(ref).max()), (name, err.max())
+    assert err.mean() <= 3e-4
+
+
+def test_bf16_stack_batch_and_ragged_length(gpu_ok):
+    """B=3, a length that is not a multiple of the 16-position chunk, against the fp32 kernels."""
+    cfg = C.bl6_laplace(1, 0)
+    sd = synth_state_dict(cfg, seed=2, flavor="trained")
+    net = HipNet.from_state_dict(cfg, sd, "cuda:0")
+    aux = torch.from_numpy(synth_aux(cfg, 3, 5))
+    T = 5 * cfg.U
+    audio = torch.rand(3, 1, T - 1, generator=torch.Generator().manual_seed(1)) * 1.6 - 0.8
+    r32, _ = net.forward(aux, audio)
+    r16 = net.forward_bf16(aux, audio)
+    assert float((r32 - r16).abs().max()) <= 3e-3 * max(1.0, float(r32.abs().max()))
+
+
+def test_bf16_unsupported_geometry_is_reported(gpu_ok):
+    cfg = C.tiny("laplace", 1, 0)
+    net = HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=2), "cuda:0")
+    with pytest.raises(RuntimeError, match="BL6-class"):
+        net.forward_bf16(torch.zeros(1, cfg.n_aux, 4), torch.zeros(1, 1, 4 * cfg.U - 1))

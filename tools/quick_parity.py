@@ -1,6 +1,6 @@
 """dev tool: decode one BL6 fixture with the library in SWN_HIP_LIB and print the max error."""
 import sys, numpy as np, torch
-sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R); sys.path.insert(0, os.path.join(_R, "tests"))
 from conftest import load_golden
 from shallow_wavenet_amd.runtime import HipNet
 from shallow_wavenet_amd.synth import synth_state_dict

@@ -2,7 +2,7 @@
    make -C shallow_wavenet_amd/csrc stamp ; SWN_HIP_LIB=shallow_wavenet_amd/libswn_hip_stamp.so python tools/stamp_decode.py)"""
 import sys
 import torch
-sys.path.insert(0, ".")
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R)
 from shallow_wavenet_amd import config as C
 from shallow_wavenet_amd.runtime import HipNet
 from shallow_wavenet_amd.synth import synth_state_dict, synth_aux

@@ -1,7 +1,7 @@
 """quick timing of the decode kernels (dev tool, not the bench contract)."""
 import sys, time
 import numpy as np, torch
-sys.path.insert(0, ".")
+import os; _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R)
 from shallow_wavenet_amd import config as C
 from shallow_wavenet_amd.runtime import HipNet
 from shallow_wavenet_amd.synth import synth_state_dict, synth_aux
