@@ -1,0 +1,237 @@
+"""Decode drivers (stage 5 / 8 of egs/shallow-wavenet/run.sh:651-708,824-878): the counterpart of
+`src/bin/decode_cswnv_laplace-shift1.py` and `src/bin/decode_dswnv_softmax.py`.
+
+Kept from the reference: CLI flags (decode_cswnv...py:117-148), length sort + `np.array_split`
+batching (:77-84), zero `pad_list` in raw feature space (:30-48), seed waveform zeros(seg) / mu-law
+class 128, all utterances of a batch run max(n_samples) steps, 16-bit PCM WAV output, the two
+summary log lines (:256-259), contiguous `np.array_split` sharding over GPUs (:200-201).
+
+Different on purpose: one process per GPU under `torchrun` (RANK/WORLD_SIZE) instead of forked
+children, and rank 0 packs the checkpoint once and broadcasts the flat parameter buffer over RCCL
+instead of every process reading the checkpoint file.  Without torchrun, `--n_gpus 1` runs in-process.
+
+Feature files: `<utt>.npy` (T x n_aux float arrays) always; `<utt>.h5` with the dataset named by
+`config.string_path` when h5py is importable (it is not in the build image).
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import json
+import logging
+import math
+import os
+import sys
+import time
+import wave
+from types import SimpleNamespace
+from typing import Iterator, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import dist as D
+from .nets import cswnv_shift1 as laplace_mod
+from .nets import dswnv as softmax_mod
+from .runtime import HipNet, pack_state_dict
+
+
+# --------------------------------------------------------------------------- feature / list I/O
+def read_feature(path: str, string_path: str = "/feat_org_lf0") -> np.ndarray:
+    if path.endswith(".npy"):
+        return np.load(path, allow_pickle=False)
+    if path.endswith(".h5"):
+        try:
+            import h5py  # noqa: WPS433  (optional dependency, absent in the build image)
+        except ImportError as e:
+            raise RuntimeError("reading .h5 features needs h5py; convert to .npy or install h5py") from e
+        with h5py.File(path, "r") as f:
+            return f[string_path][()]
+    raise RuntimeError(f"unsupported feature file {path}")
+
+
+def feature_frames(path: str, string_path: str) -> int:
+    if path.endswith(".npy"):
+        return int(np.load(path, mmap_mode="r", allow_pickle=False).shape[0])
+    return int(read_feature(path, string_path).shape[0])
+
+
+def list_features(feats: str) -> List[str]:
+    """directory -> sorted recursive *.h5 / *.npy ; file -> one path per line (utils.py:129-160)."""
+    if os.path.isdir(feats):
+        out = []
+        for ext in ("*.h5", "*.npy"):
+            out += glob.glob(os.path.join(feats, "**", ext), recursive=True)
+        return sorted(out)
+    if os.path.isfile(feats):
+        with open(feats) as f:
+            return [ln.strip() for ln in f if ln.strip()]
+    raise FileNotFoundError("--feats should be directory or list.")
+
+
+def pad_list(batch_list: Sequence[np.ndarray], pad_value: float = 0.0) -> np.ndarray:
+    """(T_i, C) arrays -> (B, T_max, C), zero padded in RAW feature space (before scale_in): the
+    last frames of a shorter utterance therefore depend on batch composition (reference quirk)."""
+    maxlen = max(b.shape[0] for b in batch_list)
+    out = np.full((len(batch_list), maxlen, batch_list[0].shape[-1]), pad_value, dtype=np.float64)
+    for i, b in enumerate(batch_list):
+        out[i, : b.shape[0]] = b
+    return out
+
+
+def plan_batches(feat_list: Sequence[str], frames: Sequence[int], batch_size: int) -> List[List[str]]:
+    """sort by frame count (np.argsort like the reference) and cut into ceil(N/bs) near-equal batches."""
+    idx = np.argsort(list(frames))
+    ordered = [feat_list[i] for i in idx]
+    n_batch = math.ceil(len(ordered) / batch_size)
+    return [a.tolist() for a in np.array_split(ordered, n_batch)]
+
+
+def decode_batches(feat_list: Sequence[str], batch_size: int, string_path: str, upsampling_factor: int
+                   ) -> Iterator[Tuple[List[str], np.ndarray, List[int]]]:
+    frames = [feature_frames(f, string_path) for f in feat_list]
+    for batch in plan_batches(feat_list, frames, batch_size):
+        hs = [read_feature(f, string_path) for f in batch]
+        ids = [os.path.splitext(os.path.basename(f))[0] for f in batch]
+        yield ids, pad_list(hs), [h.shape[0] * upsampling_factor for h in hs]
+
+
+def write_wav_pcm16(path: str, samples: np.ndarray, fs: int) -> None:
+    """float [-1,1] -> 16-bit PCM exactly as libsndfile does for soundfile.write(..., "PCM_16"):
+    lrint(x * 0x7FFF) after the caller's np.clip (decode_cswnv...py:253-254)."""
+    pcm = np.rint(np.asarray(samples, dtype=np.float64) * 32767.0).astype("<i2")
+    with wave.open(path, "wb") as w:
+        w.setnchannels(1)
+        w.setsampwidth(2)
+        w.setframerate(int(fs))
+        w.writeframes(pcm.tobytes())
+
+
+def load_config(path: str):
+    """model.conf: the pickled argparse Namespace the training script wrote (train_cswnv...py:293),
+    or the same fields as JSON."""
+    if path.endswith(".json"):
+        with open(path) as f:
+            return SimpleNamespace(**json.load(f))
+    return torch.load(path, weights_only=False)      # file written by this pipeline's own training stage
+
+
+# --------------------------------------------------------------------------- model construction
+def build_model(kind: str, config):
+    if kind == "laplace":
+        return laplace_mod.CSWNV(
+            n_aux=config.n_aux, skip_chn=config.skip_chn, hid_chn=config.hid_chn,
+            dilation_depth=config.dilation_depth, dilation_repeat=config.dilation_repeat,
+            kernel_size=config.kernel_size, aux_kernel_size=config.aux_kernel_size,
+            aux_dilation_size=config.aux_dilation_size, seg=config.seg, lpc=config.lpc,
+            aux_conv2d_flag=config.aux_conv2d_flag, wav_conv_flag=config.wav_conv_flag,
+            upsampling_factor=config.upsampling_factor)
+    return softmax_mod.DSWNV(
+        n_quantize=config.n_quantize, n_aux=config.n_aux, hid_chn=config.hid_chn, skip_chn=config.skip_chn,
+        dilation_depth=config.dilation_depth, dilation_repeat=config.dilation_repeat,
+        kernel_size=config.kernel_size, aux_kernel_size=config.aux_kernel_size,
+        aux_dilation_size=config.aux_dilation_size, audio_in_flag=getattr(config, "audio_in", False),
+        wav_conv_flag=config.wav_conv_flag, upsampling_factor=config.upsampling_factor)
+
+
+def gpu_decode(kind: str, args, config, feat_list: Sequence[str], device, packed_src_rank: int = 0):
+    """decode one shard on one GPU (decode_cswnv...py:204-259)."""
+    with torch.no_grad():
+        model = build_model(kind, config)
+        rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        cfg = model._cfg
+        if rank == packed_src_rank:
+            sd = torch.load(args.checkpoint, map_location="cpu", weights_only=True)["model"]
+            model.load_state_dict(sd)
+            packed = pack_state_dict(cfg, model.state_dict())
+        else:
+            packed = None
+        model.to(device)
+        model.eval()
+        model.set_packed_engine(HipNet(cfg, D.broadcast_packed(cfg, packed, device, src=packed_src_rank), device))
+        string_path = getattr(config, "string_path", "/feat_org_lf0")
+        t_total, n_max, n_tot = 0.0, 0, 0
+        for ids, batch_h, n_samples_list in decode_batches(feat_list, args.batch_size, string_path,
+                                                           config.upsampling_factor):
+            aux = torch.FloatTensor(batch_h).transpose(1, 2).to(device)
+            if kind == "laplace":
+                seed = torch.zeros(len(ids), model.seg, device=device)
+            else:
+                seed = torch.full((len(ids), 1), config.n_quantize // 2, dtype=torch.int64, device=device)
+            logging.info("decoding start")
+            start = time.time()
+            samples_list = model.batch_fast_generate(seed, aux, n_samples_list, args.intervals)
+            t_total += time.time() - start
+            n_max += max(n_samples_list)
+            n_tot += max(n_samples_list) * len(n_samples_list)
+            for feat_id, samples in zip(ids, samples_list):
+                wav = samples if kind == "laplace" else softmax_mod.decode_mu_law(samples, config.n_quantize)
+                write_wav_pcm16(os.path.join(args.outdir, feat_id + ".wav"), np.clip(wav, -1, 1), args.fs)
+                logging.info("wrote %s.wav in %s." % (feat_id, args.outdir))
+        if n_max:
+            logging.info("average time / sample = %.6f sec (%ld samples) [%.3f kHz/s]" % (
+                t_total / n_max, n_max, n_max / (1000 * t_total)))
+            logging.info("average throughput / sample = %.6f sec (%ld samples) [%.3f kHz/s]" % (
+                t_total / n_tot, n_tot, n_tot / (1000 * t_total)))
+        return n_tot, t_total
+
+
+def make_parser() -> argparse.ArgumentParser:
+    p = argparse.ArgumentParser()
+    p.add_argument("--feats", required=True, type=str, help="list or directory of aux feat files")
+    p.add_argument("--checkpoint", required=True, type=str, help="model file")
+    p.add_argument("--config", required=True, type=str, help="configure file")
+    p.add_argument("--outdir", required=True, type=str, help="directory to save generated samples")
+    p.add_argument("--fs", default=22050, type=int, help="sampling rate")
+    p.add_argument("--batch_size", default=1, type=int, help="number of batch size in decoding")
+    p.add_argument("--n_gpus", default=1, type=int, help="number of gpus")
+    p.add_argument("--spk_trg", default=None, type=str)
+    p.add_argument("--min_idx", default=None, type=int)
+    p.add_argument("--intervals", default=4410, type=int, help="log interval")
+    p.add_argument("--seed", default=1, type=int, help="seed number")
+    p.add_argument("--GPU_device", default=0, type=int, help="selection of GPU device")
+    p.add_argument("--GPU_device_str", default=None, type=str, help="selection of GPU device")
+    p.add_argument("--verbose", default=1, type=int, help="log level")
+    return p
+
+
+def main(kind: str, argv=None) -> int:
+    args = make_parser().parse_args(argv)
+    rank, world, local = D.init_from_env()
+    os.makedirs(args.outdir, exist_ok=True)
+    level = logging.INFO if args.verbose > 0 else logging.WARN
+    logging.basicConfig(level=level, format="%(asctime)s (%(module)s:%(lineno)d) %(levelname)s: %(message)s",
+                        datefmt="%m/%d/%Y %I:%M:%S", filename=os.path.join(args.outdir, f"decode.{rank}.log"
+                                                                       if world > 1 else "decode.log"))
+    logging.getLogger().addHandler(logging.StreamHandler())
+    os.environ["PYTHONHASHSEED"] = str(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+    config = load_config(args.config)
+    logging.info(config)
+    try:
+        feat_list = list_features(args.feats)
+    except FileNotFoundError:
+        logging.error("--feats should be directory or list.")
+        return 1
+    if world > 1 and args.n_gpus != world:
+        logging.warning("--n_gpus %d ignored: running under torchrun with %d ranks", args.n_gpus, world)
+    if world == 1 and args.n_gpus > 1:
+        logging.error("multi-GPU decode runs one process per GPU: launch with "
+                      "python -m torch.distributed.run --nproc-per-node %d ..." % args.n_gpus)
+        return 1
+    shard = D.shard_utterances(feat_list, world)[rank]
+    if not torch.cuda.is_available():
+        logging.error("no HIP device: the MI355X build has no CPU path")
+        return 1
+    if args.GPU_device_str is not None and world == 1:
+        local = int(args.GPU_device_str.split(",")[0])
+    elif world == 1:
+        local = args.GPU_device
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    gpu_decode(kind, args, config, shard, device)
+    D.barrier(device)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
