@@ -111,37 +111,37 @@ __global__ void pack_wd_kernel(const float* __restrict__ wd, int L, unsigned sho
 
 struct LayerOps {
     bf16x8 b[4];        // B fragments: K-steps 0,1 = h(t-dil) channels 0-31 / 32-63, 2,3 = h(t)
-    float4 cz[2], cc[2];// hoisted in_x rows of this lane's 8 channels (gate | candidate), first segment
+    float4 cz[4], cc[4];// hoisted in_x rows of this lane's 16 channels (gate | candidate), first segment
     float wu;           // upsampler tap of position t (seg == 1 fast path)
 };
+constexpr int NSUB = 2;  // 16-position chunks handled per loop iteration: twice the bytes in flight per wave
 
-// A wave owns one HALF of the channels (hf = 0: 0..31, hf = 1: 32..63) of a 16-position chunk: 2 gate
-// + 2 candidate M-tiles (A = 64 VGPRs resident), all four K-steps.  Two waves per SIMD fit, so the
-// MFMAs of one wave overlap the gate arithmetic of the other.
-__global__ __launch_bounds__(256, 2) void bf16_layer_kernel(const BfArgs a, const int l, const int dil, const int n_chunks) {
+// ONE wave owns all 128 rows of a 16-position chunk (A fragments of the whole layer matrix = 128
+// VGPRs, resident; one wave per SIMD with the full 512-entry register file), so every B fragment is
+// loaded exactly once; the four waves of a workgroup walk different chunks.  Measured alternatives
+// (4 waves sharing a chunk, or 2 waves each owning half the channels at 2 waves/SIMD) were 1.5-1.7x
+// slower: the vector-memory path, not MFMA, is what this kernel saturates.
+__global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, const int l, const int dil, const int n_chunks) {
     __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | bx[128] of this layer
     const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform -> scalar registers
-    const int hf = w & 1;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform -> scalar chunk arithmetic
     const int n = lane & 15, g = lane >> 4;
     cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid] : a.P[a.y.bx + (size_t)l * 128 + tid - 128];
-    bf16x8 A[4][4];                                                  // [gate m0, gate m1, cand m0, cand m1][ks]
+    bf16x8 A[8][4];
     {
         const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int mt = 0; mt < 8; ++mt)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                A[q][ks] = src[(((q >> 1) * 4 + 2 * hf + (q & 1)) * 4 + ks) * 64 + lane];
+            for (int ks = 0; ks < 4; ++ks) A[mt][ks] = src[(mt * 4 + ks) * 64 + lane];
     }
     __syncthreads();
     const size_t lstride = (size_t)a.B * a.Tp * H;
     const unsigned short* hprev = a.hs + (size_t)l * lstride;
     unsigned short* hnext = a.hs + (size_t)(l + 1) * lstride;
     const int chunks_per_b = (a.Tp + 15) / 16;
-    const int chb = 32 * hf + 8 * g;                                 // first of this lane's 8 channels
 
-    auto fetch = [&](int c, LayerOps& op) {                          // c is wave-uniform: the divisions are scalar
+    auto fetch = [&](int c, LayerOps& op) {                          // c is wave-uniform: scalar divisions
         const int b = c / chunks_per_b, t0 = (c - b * chunks_per_b) * 16, t = t0 + n;
         const unsigned short* hb = hprev + (size_t)b * a.Tp * H;
         const bool ok = t < a.Tp;
@@ -156,33 +156,45 @@ __global__ __launch_bounds__(256, 2) void bf16_layer_kernel(const BfArgs a, cons
         if (jj >= a.U) { jj -= a.U; f += 1; }
         f = f < a.Tf ? f : a.Tf - 1;
         op.wu = a.P[a.y.wup + jj];
-        const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)l * a.seg * 128 + chb;
-        op.cz[0] = *reinterpret_cast<const float4*>(cr);      op.cz[1] = *reinterpret_cast<const float4*>(cr + 4);
-        op.cc[0] = *reinterpret_cast<const float4*>(cr + H);  op.cc[1] = *reinterpret_cast<const float4*>(cr + H + 4);
+        const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)l * a.seg * 128;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // q: channel group (q>>1)*32 + 8g + 4*(q&1)
+            op.cz[q] = *reinterpret_cast<const float4*>(cr + 32 * (q >> 1) + 8 * g + 4 * (q & 1));
+            op.cc[q] = *reinterpret_cast<const float4*>(cr + H + 32 * (q >> 1) + 8 * g + 4 * (q & 1));
+        }
     };
 
-    const int stride = gridDim.x * 2;                                // chunk sequences: one per wave pair
-    int c = blockIdx.x * 2 + (w >> 1);
-    if (c >= n_chunks) return;
-    LayerOps cur, nxt;
-    fetch(c, cur);
-    for (; c < n_chunks; c += stride) {
-        const int b = c / chunks_per_b, t = (c - b * chunks_per_b) * 16 + n;
-        const int cn = c + stride;
-        if (cn < n_chunks) fetch(cn, nxt);
-        f32x4 acc[4];
+    const int stride = gridDim.x * 4 * NSUB;                         // every wave walks its own chunk sequence
+    int c0 = (blockIdx.x * 4 + w) * NSUB;
+    if (c0 >= n_chunks) return;
+    LayerOps curs[NSUB], nxts[NSUB];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int u = 0; u < NSUB; ++u) fetch(c0 + u < n_chunks ? c0 + u : n_chunks - 1, curs[u]);
+    for (; c0 < n_chunks; c0 += stride) {
+        const int cn0 = c0 + stride;
+        if (cn0 < n_chunks) {
+#pragma unroll
+            for (int u = 0; u < NSUB; ++u) fetch(cn0 + u < n_chunks ? cn0 + u : n_chunks - 1, nxts[u]);
+        }
+#pragma unroll
+      for (int u = 0; u < NSUB; ++u) {
+        const int c = c0 + u;
+        if (c >= n_chunks) break;
+        const LayerOps& cur = curs[u];
+        const int b = c / chunks_per_b, t = (c - b * chunks_per_b) * 16 + n;
+        f32x4 acc[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt) {
+            acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[q][ks], cur.b[ks], acc[q], 0, 0, 0);
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][ks], cur.b[ks], acc[mt], 0, 0, 0);
         }
         if (t < a.Tp) {
-            unsigned short hv[8];
+            unsigned short hv[16];
 #pragma unroll
-            for (int mm = 0; mm < 2; ++mm) {
-                const int c0 = chb + 4 * mm;
+            for (int m = 0; m < 4; ++m) {
+                const int c0 = chan_of(m, g, 0);
                 const float4 bdz = *reinterpret_cast<const float4*>(cst + c0);
                 const float4 bdc = *reinterpret_cast<const float4*>(cst + H + c0);
                 const float4 bxz = *reinterpret_cast<const float4*>(cst + 128 + c0);
@@ -190,8 +202,8 @@ __global__ __launch_bounds__(256, 2) void bf16_layer_kernel(const BfArgs a, cons
                 const float bdzv[4] = {bdz.x, bdz.y, bdz.z, bdz.w}, bdcv[4] = {bdc.x, bdc.y, bdc.z, bdc.w};
                 float gz[4] = {bxz.x, bxz.y, bxz.z, bxz.w}, gc[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
                 if (a.seg == 1) {
-                    const float czv[4] = {cur.cz[mm].x, cur.cz[mm].y, cur.cz[mm].z, cur.cz[mm].w};
-                    const float ccv[4] = {cur.cc[mm].x, cur.cc[mm].y, cur.cc[mm].z, cur.cc[mm].w};
+                    const float czv[4] = {cur.cz[m].x, cur.cz[m].y, cur.cz[m].z, cur.cz[m].w};
+                    const float ccv[4] = {cur.cc[m].x, cur.cc[m].y, cur.cc[m].z, cur.cc[m].w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { gz[r] = fmaf(cur.wu, czv[r], gz[r]); gc[r] = fmaf(cur.wu, ccv[r], gc[r]); }
                 } else {
@@ -207,18 +219,24 @@ __global__ __launch_bounds__(256, 2) void bf16_layer_kernel(const BfArgs a, cons
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float hp = (float)cur.b[2 + hf][mm * 4 + r];                 // h(t)[chan]: own tap-1 fragment
-                    const float z = sigm(gz[r] * (acc[mm][r] + bdzv[r]));
-                    const float cd = tanh_c(gc[r] * (acc[2 + mm][r] + bdcv[r]));
-                    hv[mm * 4 + r] = f2bf(fmaf(z, hp - cd, cd));                       // (1-z) c + z h
+                    const float hp = (float)cur.b[2 + (m >> 1)][(m & 1) * 4 + r];      // h(t)[chan]: own tap-1 fragment
+                    const float z = sigm(gz[r] * (acc[m][r] + bdzv[r]));
+                    const float cd = tanh_c(gc[r] * (acc[4 + m][r] + bdcv[r]));
+                    hv[m * 4 + r] = f2bf(fmaf(z, hp - cd, cd));                        // (1-z) c + z h
                 }
             }
-            uint4 o0;
+            uint4 o0, o1;
             o0.x = hv[0] | ((unsigned)hv[1] << 16);   o0.y = hv[2] | ((unsigned)hv[3] << 16);
             o0.z = hv[4] | ((unsigned)hv[5] << 16);   o0.w = hv[6] | ((unsigned)hv[7] << 16);
-            *reinterpret_cast<uint4*>(hnext + ((size_t)b * a.Tp + t) * H + chb) = o0;
+            o1.x = hv[8] | ((unsigned)hv[9] << 16);   o1.y = hv[10] | ((unsigned)hv[11] << 16);
+            o1.z = hv[12] | ((unsigned)hv[13] << 16); o1.w = hv[14] | ((unsigned)hv[15] << 16);
+            unsigned short* dst = hnext + ((size_t)b * a.Tp + t) * H;
+            *reinterpret_cast<uint4*>(dst + 8 * g) = o0;
+            *reinterpret_cast<uint4*>(dst + 32 + 8 * g) = o1;
         }
-        cur = nxt;
+      }
+#pragma unroll
+        for (int u = 0; u < NSUB; ++u) curs[u] = nxts[u];
     }
 }
 
@@ -409,7 +427,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     hipLaunchKernelGGL(bf16_input_kernel, dim3((unsigned)((Tp + 63) / 64), batch), dim3(256), 0, st, a);
     const int n_tiles = batch * (int)((Tp + TN - 1) / TN);
     const int n_chunks = batch * (int)((Tp + 15) / 16);
-    const int grid = (n_chunks + 1) / 2 < 512 ? (n_chunks + 1) / 2 : 512;      // persistent: 2 workgroups (8 waves) per CU, a chunk sequence per wave pair
+    const int grid = (n_chunks + 7) / 8 < 256 ? (n_chunks + 7) / 8 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
     for (int l = 0; l < g.L; ++l)
         hipLaunchKernelGGL(bf16_layer_kernel, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
     const int hgrid = n_tiles < 512 ? n_tiles : 512;

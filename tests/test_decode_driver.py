@@ -107,7 +107,13 @@ def test_driver_end_to_end_reproduces_the_reference_batch(gpu_ok, tmp_path, name
         aux[pos, :, : int(d["frames"][b])] = d["aux"][b, :, : int(d["frames"][b])]
     n_samples = [int(d["n_samples"][b]) for b in order]
     P = cpu_ref.as_params(synth_state_dict(cfg, seed=int(d["wseed"]), flavor=str(d["flavor"])))
-    g = torch.Generator().manual_seed(int(d["noise_seed"]))
+    # replay the driver's RNG use: seed, construct the module (default init draws from the same
+    # generator, as in the reference script), then the noise
+    from types import SimpleNamespace
+    np.random.seed(int(d["noise_seed"]))
+    torch.manual_seed(int(d["noise_seed"]))
+    DD.build_model(kind, SimpleNamespace(**dict(cfg.to_dict(), audio_in=cfg.audio_in_flag)))
+    g = None
     if kind == "laplace":
         noise = cpu_ref.laplace_noise(cfg, max(n_samples) // cfg.seg, len(order), generator=g)
         ref = cpu_ref.laplace_generate(cfg, P, torch.from_numpy(aux), n_samples, noise)
