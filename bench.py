@@ -34,6 +34,12 @@ from shallow_wavenet_amd.synth import synth_aux, synth_state_dict              #
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 
+# HBM bytes per decode launch from rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.csv), keyed by
+# (utterances per GPU, frames): 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes,
+# MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in bytes.  Measured offline: counters cannot be read
+# from inside this process.  Other shapes report null.
+PMC_TRAFFIC_BYTES = {(1, 600): int((2 * 1369.8 + 257.8) * 1024)}
+
 
 def algorithmic_bytes_per_position(cfg: C.NetConfig, batch: int) -> float:
     """4*W_step + 4*W_inx/U + B*(4*A0/U + state_rd + state_wr + 4)  (fp32)."""
@@ -153,7 +159,7 @@ def main():
         "real_time_factor_per_utterance": round(per_utt / 22050.0, 2),
         "us_per_sample_step": round(kern_ms * 1e3 / positions, 3),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC_BYTES.get((B, Tf)),
                      "kernel": "decode_bl6_kernel", "kernel_ms": round(kern_ms, 3),
                      "algorithmic_bytes_per_position": round(bytes_pos, 1), "positions_per_launch": positions,
                      "note": "latency-bound sequential chain; working set is L2/LDS/VGPR resident (SURVEY 7.3)"},
