@@ -78,6 +78,10 @@ int         swn_num_tensors(const swn_net_desc* d);
  * uploaded once and broadcast over RCCL (decode_cswnv_laplace-shift1.py:223-224 loads the
  * checkpoint per process instead). */
 size_t swn_packed_floats(const swn_net_desc* d);
+/* float offsets of the packed sections in the order scale_w, scale_b, aux_w[0..3], aux_b[0..3], wx, wxa, wup,
+ * bup, bx, cb, cv, cc, ct, wd, bd, wsk, bsk, w1, b1, w2, b2, total (csrc/swn_geom.hpp::SwnLayout); returns
+ * the number written (28) or a negative SWN_E_*.  Used to unfold swn_backward's packed gradients. */
+int    swn_layout_offsets(const swn_net_desc* d, size_t* out, int n);
 int    swn_pack_params(const swn_net_desc* d, const float* const* tensors_host, int n_tensors,
                        float* packed_host, size_t packed_floats);
 
@@ -151,6 +155,27 @@ int    swn_laplace_head(const swn_net_desc* d, const float* out_dev, int batch, 
                         float* mu_dev, float* b_dev, float* logb_dev, float* a_dev,
                         float* b_clip_dev, float* logb_clip_dev, int32_t* below_floor_dev,
                         void* stream);
+
+/* ---- backward of the teacher-forced stack (fp32)  (loss.backward() through CSWNV/DSWNV.forward,
+ *      train_cswnv_laplace-stftcmplx_shift1.py:724-874) ----------------------------------------------
+ *   aux_dev, cond_dev, audio_dev   the forward inputs
+ *   fe_work_dev    the work buffer swn_frontend filled (scaled features and conv_aux activations)
+ *   fwd_work_dev   the work buffer swn_forward filled (hidden states, relu(skip), relu(out_1))
+ *   hs_dev         the hidden states if swn_forward wrote them to a separate hs_dev, else NULL
+ *   grad_out_dev   (B, n_out, Tp) gradient of the loss wrt the raw out_2 outputs
+ *   work_dev       swn_backward_work_floats() scratch
+ *   gpacked_dev    swn_packed_floats() floats, ZEROED AND FILLED by the call: gradients in the packed
+ *                  parameter layout (csrc/swn_geom.hpp); the host unfolds them onto the parameters  */
+size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int n_frames);
+int    swn_backward(const swn_net_desc* d, const float* packed_dev, const float* aux_dev, const float* cond_dev,
+                    const float* fe_work_dev, const void* audio_dev, const float* fwd_work_dev,
+                    const float* hs_dev, const float* grad_out_dev, int batch, int n_frames,
+                    float* work_dev, float* gpacked_dev, void* stream);
+/* gradient of swn_laplace_head: grads wrt mu / b / logb / a (time-major, any may be NULL) -> grad wrt raw */
+int    swn_laplace_head_backward(const swn_net_desc* d, const float* out_dev, int batch, int tp,
+                                 const float* gmu_dev, const float* gb_dev, const float* glogb_dev,
+                                 const float* ga_dev, const float* gb_clip_dev, const float* glogb_clip_dev,
+                                 float* graw_dev, void* stream);
 
 #ifdef __cplusplus
 }

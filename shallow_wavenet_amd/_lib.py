@@ -50,6 +50,7 @@ SIGNATURES = {
     "swn_receptive_field": (c_int, [POINTER(NetDesc)]),
     "swn_num_tensors": (c_int, [POINTER(NetDesc)]),
     "swn_packed_floats": (c_size_t, [POINTER(NetDesc)]),
+    "swn_layout_offsets": (c_int, [POINTER(NetDesc), POINTER(c_size_t), c_int]),
     "swn_pack_params": (c_int, [POINTER(NetDesc), POINTER(c_void_p), c_int, c_void_p, c_size_t]),
     "swn_frontend_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_cond_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
@@ -65,6 +66,11 @@ SIGNATURES = {
     "swn_forward_bf16_work_bytes": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward_bf16": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                  c_void_p, c_void_p, c_void_p]),
+    "swn_backward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
+    "swn_backward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                             c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "swn_laplace_head_backward": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "swn_laplace_head": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }

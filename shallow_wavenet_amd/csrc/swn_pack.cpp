@@ -44,6 +44,20 @@ extern "C" size_t swn_packed_floats(const swn_net_desc* d) {
     return y.total;
 }
 
+// float offsets of the packed sections, fixed order (mirrored by shallow_wavenet_amd/runtime.py LAYOUT_FIELDS)
+extern "C" int swn_layout_offsets(const swn_net_desc* d, size_t* out, int n) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    if (rc < 0) return rc;
+    SwnLayout y; swn_make_layout(&g, &y);
+    const size_t v[] = {y.scale_w, y.scale_b, y.aux_w[0], y.aux_w[1], y.aux_w[2], y.aux_w[3], y.aux_b[0], y.aux_b[1],
+                        y.aux_b[2], y.aux_b[3], y.wx, y.wxa, y.wup, y.bup, y.bx, y.cb, y.cv, y.cc, y.ct, y.wd, y.bd,
+                        y.wsk, y.bsk, y.w1, y.b1, y.w2, y.b2, y.total};
+    const int cnt = (int)(sizeof(v) / sizeof(v[0]));
+    if (!out || n < cnt) return SWN_E_BADARG;
+    for (int i = 0; i < cnt; ++i) out[i] = v[i];
+    return cnt;
+}
+
 extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int n_tensors,
                                float* out, size_t out_floats) {
     SwnGeom g; int rc = swn_make_geom(d, &g);

@@ -1,0 +1,468 @@
+// Backward pass of the teacher-forced stack (fp32) - the GPU side of the reference's
+// loss.backward() through CSWNV.forward / DSWNV.forward (train_cswnv...py:724-874).
+//
+// Gradients are produced in the PACKED parameter layout (csrc/swn_geom.hpp) into a zeroed buffer;
+// the host unfolds them onto the reference's nn.Parameters (nets/_autograd.py).  Two generic fp32
+// kernels do all contractions:
+//   time_gemm_kernel    Y[b][m][t] (op)= sum_{tap,c} A(m,tap,c) * X[b][c][t + sgn*(tap-center)*dil]
+//                       (conv forward / data-gradient of a dilated conv / plain 1x1, zero outside [0,T))
+//   reduce_gemm_kernel  G[m][tap][c] += sum_{b,t} P[b][m][t] * Q[b][c][t + sgn*(tap-center)*dil]
+//                       (weight gradients; split over time blocks, float atomics)
+// plus element-wise kernels for the gate, the rank-1 upsampler / hoisted in_x, the input layer and
+// the Laplace head.  Hidden states h_0..h_L saved by the forward are reused; the gate pre-activations
+// are recomputed (one extra conv GEMM per layer) instead of being stored.
+#include <hip/hip_runtime.h>
+#include "swn_geom.hpp"
+
+namespace {
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+
+struct TimeGemm {
+    const float* A; long a_sm, a_stap, a_sc;        // A(m, tap, c)
+    const float* X; long x_sb, x_sc, x_st;          // X[b][c][t]
+    float* Y; long y_sb, y_sm;                      // Y[b][m][t], t contiguous
+    const float* mask; long k_sb, k_sm;             // optional relu mask (same indexing as Y): keep where mask > 0
+    int M, taps, KC, T, sgn, center, dil, accumulate;
+};
+
+// 64(m) x 64(t) tile, BK = 16 over k = (tap, c); thread = 4 x 4.
+__global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
+    __shared__ float As[16][64 + 4];
+    __shared__ float Bs[16][64 + 4];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const float* Xb = g.X + (size_t)b * g.x_sb;
+    const int Kd = g.taps * g.KC;
+    float acc[4][4] = {};
+    for (int k0 = 0; k0 < Kd; k0 += 16) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e & 15, mm = e >> 4;
+            const int k = k0 + kk, m = m0 + mm;
+            float v = 0.f;
+            if (k < Kd && m < g.M) { const int tap = k / g.KC, c = k - tap * g.KC; v = g.A[m * g.a_sm + tap * g.a_stap + c * g.a_sc]; }
+            As[kk][mm] = v;
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e >> 6, tt = e & 63;
+            const int k = k0 + kk;
+            float v = 0.f;
+            if (k < Kd) {
+                const int tap = k / g.KC, c = k - tap * g.KC;
+                const int ts = t0 + tt + g.sgn * (tap - g.center) * g.dil;
+                if (ts >= 0 && ts < g.T && t0 + tt < g.T) v = Xb[c * g.x_sc + ts * g.x_st];
+            }
+            Bs[kk][tt] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float4 aa = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
+            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
+            const float av[4] = {aa.x, aa.y, aa.z, aa.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * ty + r;
+        if (m >= g.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 4 * tx + j;
+            if (t >= g.T) continue;
+            float v = acc[r][j];
+            if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
+            float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
+            *y = g.accumulate ? *y + v : v;
+        }
+    }
+}
+
+struct ReduceGemm {
+    const float* P; long p_sb, p_sm, p_st;          // P[b][m][t]
+    const float* Q; long q_sb, q_sc, q_st;          // Q[b][c][t]
+    float* G; long g_sm, g_stap, g_sc;              // G(m, tap, c)  += ...
+    float* gb;                                      // optional: gb[m] += sum_{b,t} P
+    int M, taps, KC, T, sgn, center, dil, TS;       // TS: time positions per block
+};
+
+__global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
+    __shared__ float Ps[16][64 + 4];
+    __shared__ float Qs[16][64 + 4];
+    const int nseg = (g.T + g.TS - 1) / g.TS;
+    const int b = blockIdx.z / nseg, ts0 = (blockIdx.z - b * nseg) * g.TS;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int Nc = g.taps * g.KC;
+    const float* Pb = g.P + (size_t)b * g.p_sb;
+    const float* Qb = g.Q + (size_t)b * g.q_sb;
+    float acc[4][4] = {};
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tend = ts0 + g.TS < g.T ? ts0 + g.TS : g.T;
+    for (int t0 = ts0; t0 < tend; t0 += 16) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e & 15, mm = e >> 4;        // time fastest: coalesced when p_st == 1
+            const int t = t0 + kk, m = m0 + mm;
+            Ps[kk][mm] = (t < tend && m < g.M) ? Pb[m * g.p_sm + t * g.p_st] : 0.f;
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int kk = e & 15, nn = e >> 4;
+            const int t = t0 + kk, nc = n0 + nn;
+            float v = 0.f;
+            if (t < tend && nc < Nc) {
+                const int tap = nc / g.KC, c = nc - tap * g.KC;
+                const int tsrc = t + g.sgn * (tap - g.center) * g.dil;
+                if (tsrc >= 0 && tsrc < g.T) v = Qb[c * g.q_sc + tsrc * g.q_st];
+            }
+            Qs[kk][nn] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const float4 aa = *reinterpret_cast<const float4*>(&Ps[kk][4 * ty]);
+            const float4 bb = *reinterpret_cast<const float4*>(&Qs[kk][4 * tx]);
+            const float av[4] = {aa.x, aa.y, aa.z, aa.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                rs[r] += av[r];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = m0 + 4 * ty + r;
+        if (m >= g.M) continue;
+        if (g.gb && blockIdx.y == 0 && tx == 0) atomicAdd(g.gb + m, rs[r]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int nc = n0 + 4 * tx + j;
+            if (nc >= Nc) continue;
+            const int tap = nc / g.KC, c = nc - tap * g.KC;
+            atomicAdd(g.G + m * g.g_sm + tap * g.g_stap + c * g.g_sc, acc[r][j]);
+        }
+    }
+}
+
+// ---- gate backward: recomputed pre-activations a (B,2H,T) -> da, dgx (in place over a / second buffer),
+//      and the highway carry  dh_prev += dh * z.      (cswnv_shift1.py:276-278)
+struct GateBwd {
+    SwnGeom g; SwnLayout y;
+    const float* P; const float* cond; const void* audio;
+    const float* hs; float* dhs; float* a_da; float* dgx;
+    int B, Tf, Tp, coff, l;
+};
+
+template <int KIND>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
+    const SwnGeom& g = a.g;
+    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (t >= a.Tp) return;
+    const int H = g.H, H2 = 2 * g.H, l = a.l, seg = g.seg;
+    const float* P = a.P;
+    const size_t hb = ((size_t)b * (g.L + 1)) * H * a.Tp;
+    const float hprev = a.hs[hb + ((size_t)l * H + o) * a.Tp + t];
+    const float dh = a.dhs[hb + ((size_t)(l + 1) * H + o) * a.Tp + t];
+    float* az = a.a_da + ((size_t)b * H2 + o) * a.Tp + t;
+    float* ac = a.a_da + ((size_t)b * H2 + H + o) * a.Tp + t;
+    float gz = P[a.y.bx + (size_t)l * H2 + o], gc = P[a.y.bx + (size_t)l * H2 + H + o];
+    const float* condb = a.cond + (size_t)b * a.Tf * g.N;
+    for (int s = 0; s < seg; ++s) {
+        const int tt = t + s + a.coff;
+        int f = tt / g.U; const int jj = tt - f * g.U;
+        f = f < a.Tf ? f : a.Tf - 1;
+        const float w = P[a.y.wup + jj];
+        const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+        gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
+    }
+    if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
+        int idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q; idx = idx < 0 ? idx + g.Q : idx;
+        const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
+        gz += wa[o]; gc += wa[H + o];
+    }
+    const float sz = *az + P[a.y.bd + (size_t)l * H2 + o], sc = *ac + P[a.y.bd + (size_t)l * H2 + H + o];
+    const float z = sigm(gz * sz), c = tanhf(gc * sc);
+    const float dz = dh * (hprev - c) * z * (1.f - z);      // d/d(gz*sz)
+    const float dc = dh * (1.f - z) * (1.f - c * c);        // d/d(gc*sc)
+    *az = dz * gz; *ac = dc * gc;                           // da
+    a.dgx[((size_t)b * H2 + o) * a.Tp + t] = dz * sz;
+    a.dgx[((size_t)b * H2 + H + o) * a.Tp + t] = dc * sc;
+    a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z;   // highway path
+}
+
+// ---- hoisted conditioning backward, two orientations of the same (frame x tap) product:
+//      cond_bwd_kernel  thread = in_x row o2:  dcond[b][f][(l*seg+s)*2H+o2] = sum_jj w_up[jj] * dgx[o2][t] ; gbx
+//      wup_bwd_kernel   thread = upsampler tap jj:  gwup[jj] += sum_{s,o2} dgx[o2][t] * cond[b][f][(l*seg+s)*2H+o2]
+//      with t = f*U + jj - s - coff  (the positions whose conditioning comes from frame f, tap jj)
+__global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* __restrict__ dcond, float* __restrict__ gbx) {
+    const SwnGeom& g = a.g;
+    const int o2 = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y, b = blockIdx.z;
+    const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
+    if (o2 >= H2) return;
+    const float* dg = a.dgx + ((size_t)b * H2 + o2) * a.Tp;
+    float bsum = 0.f;
+    for (int s = 0; s < seg; ++s) {
+        float dsum = 0.f;
+        for (int jj = 0; jj < U; ++jj) {
+            const int t = f * U + jj - s - a.coff;
+            if (t < 0 || t >= a.Tp) continue;
+            const float d = dg[t];
+            dsum = fmaf(a.P[a.y.wup + jj], d, dsum);
+            if (s == 0) bsum += d;                           // every position belongs to exactly one (f, jj) at s = 0
+        }
+        dcond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + s) * H2 + o2] = dsum;
+    }
+    atomicAdd(gbx + (size_t)l * H2 + o2, bsum);
+}
+
+__global__ __launch_bounds__(256) void wup_bwd_kernel(const GateBwd a, float* __restrict__ gwup) {
+    const SwnGeom& g = a.g;
+    const int jj = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
+    const int H2 = 2 * g.H, l = a.l, seg = g.seg;
+    if (jj >= g.U) return;
+    const float* condb = a.cond + ((size_t)b * a.Tf + f) * g.N;
+    float acc = 0.f;
+    for (int s = 0; s < seg; ++s) {
+        const int t = f * g.U + jj - s - a.coff;
+        if (t < 0 || t >= a.Tp) continue;
+        const float* dg = a.dgx + (size_t)b * H2 * a.Tp + t;
+        const float* cr = condb + (size_t)(l * seg + s) * H2;
+        for (int o2 = 0; o2 < H2; ++o2) acc = fmaf(dg[(size_t)o2 * a.Tp], cr[o2], acc);
+    }
+    atomicAdd(gwup + jj, acc);
+}
+
+// ---- input layer backward: dh0 -> gcb, gcv, gcc (laplace) | gct (softmax)
+template <int KIND>
+__global__ __launch_bounds__(256) void input_bwd_kernel(const GateBwd a, float* __restrict__ gP) {
+    const SwnGeom& g = a.g;
+    const int o = blockIdx.x, b = blockIdx.y, K = g.K, H = g.H;
+    const float* P = a.P;
+    const float* dh0 = a.dhs + ((size_t)b * (g.L + 1)) * H * a.Tp + (size_t)o * a.Tp;
+    float scb = 0.f, sv[8] = {0.f}, sc[8] = {0.f};
+    for (int t = threadIdx.x; t < a.Tp; t += 256) {
+        float pre = P[a.y.cb + o];
+        if (KIND == SWN_KIND_LAPLACE) {
+            const float* au = reinterpret_cast<const float*>(a.audio) + (size_t)b * (a.Tp + g.seg - 1);
+            const int ai = t + g.seg - 1;
+            for (int k = 0; k < K; ++k) { const int r = ai - (K - 1 - k); if (r >= 0) pre += fmaf(P[a.y.cv + (size_t)k * H + o], au[r], P[a.y.cc + (size_t)k * H + o]); }
+            const float d = dh0[t] / ((1.f + fabsf(pre)) * (1.f + fabsf(pre)));
+            scb += d;
+            for (int k = 0; k < K && k < 8; ++k) { const int r = ai - (K - 1 - k); if (r >= 0) { sv[k] = fmaf(d, au[r], sv[k]); sc[k] += d; } }
+        } else {
+            const int* au = reinterpret_cast<const int*>(a.audio) + (size_t)b * a.Tp;
+            int idxs[8];
+            for (int k = 0; k < K && k < 8; ++k) {
+                const int r = t - (K - 1 - k);
+                idxs[k] = -1;
+                if (r >= 0) { int idx = au[r] % g.Q; idx = idx < 0 ? idx + g.Q : idx; idxs[k] = idx; pre += P[a.y.ct + ((size_t)k * g.Q + idx) * H + o]; }
+            }
+            const float d = dh0[t] / ((1.f + fabsf(pre)) * (1.f + fabsf(pre)));
+            scb += d;
+            for (int k = 0; k < K && k < 8; ++k) if (idxs[k] >= 0) atomicAdd(gP + a.y.ct + ((size_t)k * g.Q + idxs[k]) * H + o, d);
+        }
+    }
+    // block reduction through atomics (H blocks x B): cheap at this size
+    atomicAdd(gP + a.y.cb + o, scb);
+    if (KIND == SWN_KIND_LAPLACE)
+        for (int k = 0; k < K && k < 8; ++k) { atomicAdd(gP + a.y.cv + (size_t)k * H + o, sv[k]); atomicAdd(gP + a.y.cc + (size_t)k * H + o, sc[k]); }
+}
+
+// ---- Laplace head backward: grads wrt (mu, b, logb, a) time-major -> grad wrt raw (B, NO, Tp)
+__global__ __launch_bounds__(256) void laplace_head_bwd_kernel(const float* __restrict__ raw, int Tp, int seg, int lpc,
+                                                               const float* gmu, const float* gb, const float* glogb,
+                                                               const float* ga, const float* gbc, const float* glc,
+                                                               float* __restrict__ graw) {
+    const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (t >= Tp) return;
+    const int NO = 2 * seg + lpc;
+    for (int j = 0; j < seg; ++j) {
+        const size_t o = ((size_t)b * Tp + t) * seg + j;
+        graw[((size_t)b * NO + j) * Tp + t] = gmu ? gmu[o] : 0.f;
+        const float y = raw[((size_t)b * NO + seg + j) * Tp + t];
+        const float s = sigm(y), bb = s;                    // b = exp(logsigmoid(y)) = sigmoid(y)
+        float dlog = (glogb ? glogb[o] : 0.f) + (gb ? gb[o] * bb : 0.f);           // d/dlogb
+        // clipped copies (logb floored at -14.1621): gradient flows only where the floor is inactive
+        const float lb = fminf(y, 0.f) - log1pf(expf(-fabsf(y)));
+        if (lb >= -14.162084148244246758816564788835f) dlog += (glc ? glc[o] : 0.f) + (gbc ? gbc[o] * bb : 0.f);
+        graw[((size_t)b * NO + seg + j) * Tp + t] = dlog * (1.f - s);            // dlogsigmoid/dy = 1 - sigmoid(y)
+    }
+    for (int k = 0; k < lpc; ++k)
+        graw[((size_t)b * NO + 2 * seg + k) * Tp + t] = ga ? ga[((size_t)b * Tp + t) * lpc + k] : 0.f;
+}
+
+size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
+
+void launch_time(const TimeGemm& g, int B, hipStream_t st) {
+    hipLaunchKernelGGL(time_gemm_kernel, dim3((g.T + 63) / 64, (g.M + 63) / 64, B), dim3(256), 0, st, g);
+}
+void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
+    g.TS = 512;
+    const int nseg = (g.T + g.TS - 1) / g.TS;
+    hipLaunchKernelGGL(reduce_gemm_kernel, dim3((g.M + 63) / 64, (g.taps * g.KC + 63) / 64, B * nseg), dim3(256), 0, st, g);
+}
+
+}  // namespace
+
+extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    const long T = (long)n_frames * g.U;
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
+    if (Tp < 1) return 0;
+    size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
+    return r64((size_t)batch * g.O1 * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * (g.L + 1) * g.H * Tp) +
+           2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames);
+}
+
+extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
+                            const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
+                            const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
+    GateBwd ga;
+    int rc = swn_make_geom(d, &ga.g);
+    if (rc < 0) return rc;
+    const SwnGeom& g = ga.g;
+    if (!packed || !aux || !cond || !fe_work || !audio || !fwd_work || !grad_out || !work || !gpacked ||
+        batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+    if (g.Hp != g.H || g.K > 8 || g.U > 256) return SWN_E_UNSUPPORTED;
+    swn_make_layout(&ga.g, &ga.y);
+    const SwnLayout& y = ga.y;
+    const long T = (long)n_frames * g.U;
+    const int Tp = (int)(g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1);
+    if (Tp < 1) return SWN_E_BADARG;
+    hipStream_t st = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    const int B = batch, H = g.H, H2 = 2 * g.H, L = g.L, S = g.S, O1 = g.O1, NO = g.NO;
+    // forward buffers (layout of swn_forward_work_floats): hs | s1 = relu(skip) | r1 = relu(out_1)
+    const size_t hs_floats = r64((size_t)B * (L + 1) * H * Tp);
+    const float* hs = hs_opt ? hs_opt : fwd_work;
+    const float* s1 = fwd_work + hs_floats;
+    const float* r1 = s1 + r64((size_t)B * S * Tp);
+    // scratch
+    float* do1 = work;
+    float* dskip = do1 + r64((size_t)B * O1 * Tp);
+    float* dhs = dskip + r64((size_t)B * S * Tp);
+    float* a_da = dhs + r64((size_t)B * (L + 1) * H * Tp);
+    float* dgx = a_da + r64((size_t)B * H2 * Tp);
+    float* dcond = dgx + r64((size_t)B * H2 * Tp);
+    float* dfe = dcond + r64((size_t)B * n_frames * g.N);
+    if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
+    if (hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
+    const long hsb = (long)(L + 1) * H * Tp;
+
+    // ---- head: out_2, out_1, skip
+    {   // do1 = relu'(r1) . W2^T dY ; gW2 += dY r1^T
+        TimeGemm t = {packed + y.w2, 1, 0, g.O1p, grad_out, (long)NO * Tp, Tp, 1, do1, (long)O1 * Tp, Tp, r1, (long)O1 * Tp, Tp,
+                      O1, 1, NO, Tp, 1, 0, 1, 0};
+        launch_time(t, B, st);
+        ReduceGemm r = {grad_out, (long)NO * Tp, Tp, 1, r1, (long)O1 * Tp, Tp, 1, gpacked + y.w2, g.O1p, 0, 1, gpacked + y.b2,
+                        NO, 1, O1, Tp, 1, 0, 1, 0};
+        launch_reduce(r, B, st);
+    }
+    {   // dskip = relu'(s1) . W1^T do1 ; gW1 += do1 s1^T
+        TimeGemm t = {packed + y.w1, 1, 0, g.Sp, do1, (long)O1 * Tp, Tp, 1, dskip, (long)S * Tp, Tp, s1, (long)S * Tp, Tp,
+                      S, 1, O1, Tp, 1, 0, 1, 0};
+        launch_time(t, B, st);
+        ReduceGemm r = {do1, (long)O1 * Tp, Tp, 1, s1, (long)S * Tp, Tp, 1, gpacked + y.w1, g.Sp, 0, 1, gpacked + y.b1,
+                        O1, 1, S, Tp, 1, 0, 1, 0};
+        launch_reduce(r, B, st);
+    }
+    {   // dh_l (skip part) = Wsk_l^T dskip for all l at once ; gWsk += dskip hcat^T
+        TimeGemm t = {packed + y.wsk, 1, 0, (long)L * g.Hp, dskip, (long)S * Tp, Tp, 1, dhs + (size_t)H * Tp, hsb, Tp, nullptr, 0, 0,
+                      L * H, 1, S, Tp, 1, 0, 1, 0};
+        launch_time(t, B, st);
+        ReduceGemm r = {dskip, (long)S * Tp, Tp, 1, hs + (size_t)H * Tp, hsb, Tp, 1, gpacked + y.wsk, (long)L * g.Hp, 0, 1, gpacked + y.bsk,
+                        S, 1, L * H, Tp, 1, 0, 1, 0};
+        launch_reduce(r, B, st);
+    }
+    // ---- layers, last to first
+    ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx;
+    ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    for (int l = L - 1; l >= 0; --l) {
+        ga.l = l;
+        const float* Wd = packed + y.wd + (size_t)l * H2 * g.K * g.Hp;                 // [o2][tap][i]
+        {   // a = Wd (*) h_{l-1}   (bias added in the gate kernel)
+            TimeGemm t = {Wd, (long)g.K * g.Hp, g.Hp, 1, hs + (size_t)l * H * Tp, hsb, Tp, 1, a_da, (long)H2 * Tp, Tp, nullptr, 0, 0,
+                          H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
+            launch_time(t, B, st);
+        }
+        {
+            dim3 grid((Tp + 255) / 256, H, B);
+            if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(gate_bwd_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, ga);
+            else hipLaunchKernelGGL(gate_bwd_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, ga);
+        }
+        {   // gWd += da X^T (taps shifted back), gbd += rowsum(da)
+            ReduceGemm r = {a_da, (long)H2 * Tp, Tp, 1, hs + (size_t)l * H * Tp, hsb, Tp, 1,
+                            gpacked + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, gpacked + y.bd + (size_t)l * H2,
+                            H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
+            launch_reduce(r, B, st);
+        }
+        {   // dh_{l-1} += Wd^T (*) da  (taps shifted forward): A(m=i, tap, c=o2) = Wd[o2][tap][i]
+            TimeGemm t = {Wd, 1, g.Hp, (long)g.K * g.Hp, a_da, (long)H2 * Tp, Tp, 1, dhs + (size_t)l * H * Tp, hsb, Tp, nullptr, 0, 0,
+                          H, g.K, H2, Tp, -1, g.K - 1, g.dil[l], 1};
+            launch_time(t, B, st);
+        }
+        hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 255) / 256, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx);
+        hipLaunchKernelGGL(wup_bwd_kernel, dim3(n_frames, B), dim3(256), 0, st, ga, gpacked + y.wup);
+    }
+    // ---- input layer
+    if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_LAPLACE>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
+    else hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_SOFTMAX>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
+    // ---- frame-rate front end: cond = Wx . C ; C = conv_aux(scale_in(aux))
+    {
+        const size_t bt = (size_t)B * n_frames;
+        // forward activations inside fe_work: scaled | aux conv outputs...
+        const float* act[SWN_MAXAUX + 1]; float* dact[SWN_MAXAUX + 1];
+        int chn[SWN_MAXAUX + 1];
+        const float* p = fe_work; float* q = dfe;
+        chn[0] = g.n_aux; act[0] = p; dact[0] = q; p += bt * g.n_aux; q += bt * g.n_aux;
+        for (int i = 0; i < g.auxl; ++i) { chn[i + 1] = g.aux_cout[i]; act[i + 1] = p; dact[i + 1] = q; p += bt * g.aux_cout[i]; q += bt * g.aux_cout[i]; }
+        const float* C = act[g.auxl];
+        {   // dC[b][c][f] = sum_n Wx[n][c] dcond[b][f][n] ; gWx[n][c] += sum_{b,f} dcond[b][f][n] C[b][c][f]
+            TimeGemm t = {packed + y.wx, 1, 0, g.A0p, dcond, (long)n_frames * g.N, 1, g.N, dact[g.auxl], (long)g.A0 * n_frames, n_frames,
+                          nullptr, 0, 0, g.A0, 1, g.N, n_frames, 1, 0, 1, 0};
+            launch_time(t, B, st);
+            ReduceGemm r = {dcond, (long)n_frames * g.N, 1, g.N, C, (long)g.A0 * n_frames, n_frames, 1, gpacked + y.wx, g.A0p, 0, 1, nullptr,
+                            g.N, 1, g.A0, n_frames, 1, 0, 1, 0};
+            launch_reduce(r, B, st);
+        }
+        for (int i = g.auxl - 1; i >= 0; --i) {
+            const int ci = g.aux_cin[i], co = g.aux_cout[i], ks = g.auxk, half = (g.auxk - 1) / 2, dl = g.aux_dil[i];
+            {   // gW[co][ci][k] += sum dY[co][f] X[ci][f + (k-half)*dil] ; gb
+                ReduceGemm r = {dact[i + 1], (long)co * n_frames, n_frames, 1, act[i], (long)ci * n_frames, n_frames, 1,
+                                gpacked + y.aux_w[i], (long)ci * ks, 1, ks, gpacked + y.aux_b[i], co, ks, ci, n_frames, 1, half, dl, 0};
+                launch_reduce(r, B, st);
+            }
+            {   // dX[ci][f] = sum_{k,co} W[co][ci][k] dY[co][f - (k-half)*dil]
+                TimeGemm t = {packed + y.aux_w[i], ks, 1, (long)ci * ks, dact[i + 1], (long)co * n_frames, n_frames, 1, dact[i],
+                              (long)ci * n_frames, n_frames, nullptr, 0, 0, ci, ks, co, n_frames, -1, half, dl, 0};
+                launch_time(t, B, st);
+            }
+        }
+        {   // scale_in: 1x1 on the raw features
+            ReduceGemm r = {dact[0], (long)g.n_aux * n_frames, n_frames, 1, aux, (long)g.n_aux * n_frames, n_frames, 1,
+                            gpacked + y.scale_w, g.n_aux, 0, 1, gpacked + y.scale_b, g.n_aux, 1, g.n_aux, n_frames, 1, 0, 1, 0};
+            launch_reduce(r, B, st);
+        }
+    }
+    return swn_launch_status("swn_backward");
+}
+
+extern "C" int swn_laplace_head_backward(const swn_net_desc* d, const float* raw, int batch, int tp, const float* gmu,
+                                         const float* gb, const float* glogb, const float* ga, const float* gbc,
+                                         const float* glc, float* graw, void* stream_) {
+    SwnGeom g; int rc = swn_make_geom(d, &g);
+    if (rc < 0) return rc;
+    if (g.kind != SWN_KIND_LAPLACE) return SWN_E_BADDESC;
+    if (!raw || !graw || batch < 1 || batch > 65535 || tp < 1) return SWN_E_BADARG;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(laplace_head_bwd_kernel, dim3((tp + 255) / 256, batch), dim3(256), 0, (hipStream_t)stream_,
+                       raw, tp, g.seg, g.lpc, gmu, gb, glogb, ga, gbc, glc, graw);
+    return swn_launch_status("swn_laplace_head_backward");
+}

@@ -107,11 +107,18 @@ class CSWNV(EngineMixin, nn.Module):
         seg==1 and lpc==0 returns 2-D (B, T') tensors (cswnv_shift1.py:228-267)."""
         if do and self.do_prob > 0:
             raise NotImplementedError("dropout (do=True) is a training feature that is not built yet")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward of the HIP stack is not built yet: call under torch.no_grad()")
         net = self._engine()
-        raw, _ = net.forward(aux, audio)
-        mu, b, log_b, a, b_clip, log_b_clip, flag = net.laplace_head(raw, clip=clip)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: HIP forward + HIP backward behind autograd Functions (nets/_autograd.py)
+            from shallow_wavenet_amd.nets._autograd import LaplaceHeadFunction, StackFunction
+            raw = StackFunction.apply(self, aux, audio, *self.parameters())
+            mu, b, log_b, a, b_clip, log_b_clip, flag = LaplaceHeadFunction.apply(net, raw, clip)
+            a = a if self.lpc > 0 else None
+            if not clip:
+                b_clip = log_b_clip = None
+        else:
+            raw, _ = net.forward(aux, audio)
+            mu, b, log_b, a, b_clip, log_b_clip, flag = net.laplace_head(raw, clip=clip)
         if self.lpc == 0 and self.seg == 1:
             sq = lambda x: None if x is None else x.reshape(x.shape[0], -1)
             mu, b, log_b, b_clip, log_b_clip = sq(mu), sq(b), sq(log_b), sq(b_clip), sq(log_b_clip)

@@ -128,10 +128,13 @@ class DSWNV(EngineMixin, nn.Module):
         aux (B, n_aux, Tf) -> logits (B, Tf*U-1, Q)."""
         if do and self.do_prob > 0:
             raise NotImplementedError("dropout (do=True) is a training feature that is not built yet")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward of the HIP stack is not built yet: call under torch.no_grad()")
         net = self._engine()
-        raw, _ = net.forward(aux, self._indices(audio, self.n_quantize))
+        idx = self._indices(audio, self.n_quantize)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from shallow_wavenet_amd.nets._autograd import StackFunction
+            raw = StackFunction.apply(self, aux, idx, *self.parameters())
+        else:
+            raw, _ = net.forward(aux, idx)
         return raw.transpose(1, 2)
 
     def batch_fast_generate(self, audio, aux, n_samples_list, intervals=4410):

@@ -51,6 +51,21 @@ def pack_state_dict(cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Te
     return packed
 
 
+LAYOUT_FIELDS = ("scale_w", "scale_b", "aux_w0", "aux_w1", "aux_w2", "aux_w3", "aux_b0", "aux_b1", "aux_b2", "aux_b3",
+                 "wx", "wxa", "wup", "bup", "bx", "cb", "cv", "cc", "ct", "wd", "bd", "wsk", "bsk", "w1", "b1", "w2",
+                 "b2", "total")
+
+
+def layout_offsets(cfg: NetConfig) -> Dict[str, int]:
+    """float offsets of the packed sections (swn_layout_offsets)."""
+    d = _lib.desc_from_cfg(cfg)
+    buf = (ctypes.c_size_t * len(LAYOUT_FIELDS))()
+    n = _lib.lib().swn_layout_offsets(ctypes.byref(d), buf, len(LAYOUT_FIELDS))
+    if n != len(LAYOUT_FIELDS):
+        _lib.check(n if n < 0 else -2, "layout_offsets")
+    return {k: int(buf[i]) for i, k in enumerate(LAYOUT_FIELDS)}
+
+
 class HipNet:
     """One network's packed parameters resident in HBM plus the launch helpers."""
 
@@ -81,6 +96,7 @@ class HipNet:
         with torch.cuda.device(self.device):
             _lib.check(L.swn_frontend(d, _ptr(self.packed), _ptr(aux), B, Tf, _ptr(work), _ptr(cond),
                                       _stream_ptr(self.device)), "frontend")
+        self._last_frontend_work = work            # kept for swn_backward (conv_aux activations)
         return cond.view(B, Tf, -1)
 
     # ------------------------------------------------------------------ decode
@@ -182,3 +198,48 @@ class HipNet:
                                           _ptr(logb), _ptr(a), _ptr(bc), _ptr(lc), _ptr(flag),
                                           _stream_ptr(self.device)), "laplace_head")
         return mu, b, logb, a, bc, lc, flag
+
+
+    # ------------------------------------------------------------------ training (fp32)
+    def forward_train(self, aux: torch.Tensor, audio: torch.Tensor):
+        """forward that keeps what swn_backward needs: returns (raw, saved) ."""
+        cfg = self.cfg
+        aux = aux.to(self.device, torch.float32).contiguous()
+        cond = self.frontend(aux)
+        fe_work = self._last_frontend_work
+        soft = cfg.kind == "softmax"
+        B, Tf = cond.shape[0], cond.shape[1]
+        T = Tf * cfg.U
+        Tp = T - 1 if soft else T - 2 * cfg.seg + 1
+        audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
+        d = ctypes.byref(self.desc)
+        work = torch.empty(self.lib.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
+                                            _ptr(out), _ptr(None), _stream_ptr(self.device)), "forward")
+        return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
+
+    def backward(self, saved, grad_raw: torch.Tensor) -> torch.Tensor:
+        """gradient of the loss wrt the packed parameter buffer, given d loss / d raw (B, n_out, Tp)."""
+        L, d = self.lib, ctypes.byref(self.desc)
+        B, Tf = saved["B"], saved["Tf"]
+        grad_raw = grad_raw.to(self.device, torch.float32).contiguous()
+        work = torch.empty(L.swn_backward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        gp = torch.empty_like(self.packed)
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_backward(d, _ptr(self.packed), _ptr(saved["aux"]), _ptr(saved["cond"]), _ptr(saved["fe_work"]),
+                                      _ptr(saved["audio"]), _ptr(saved["work"]), _ptr(None), _ptr(grad_raw), B, Tf,
+                                      _ptr(work), _ptr(gp), _stream_ptr(self.device)), "backward")
+        return gp
+
+    def laplace_head_backward(self, raw, gmu, gb, glogb, ga, gb_clip=None, glogb_clip=None) -> torch.Tensor:
+        B, NO, Tp = raw.shape
+        c = lambda t: None if t is None else t.to(self.device, torch.float32).contiguous()
+        gmu, gb, glogb, ga, gb_clip, glogb_clip = c(gmu), c(gb), c(glogb), c(ga), c(gb_clip), c(glogb_clip)
+        graw = torch.empty_like(raw)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.swn_laplace_head_backward(ctypes.byref(self.desc), _ptr(raw), B, Tp, _ptr(gmu), _ptr(gb),
+                                                          _ptr(glogb), _ptr(ga), _ptr(gb_clip), _ptr(glogb_clip),
+                                                          _ptr(graw), _stream_ptr(self.device)), "laplace_head_backward")
+        return graw

@@ -38,7 +38,7 @@ def run(cfg, B, Tf, variants=(1, 2), reps=3):
         if soft: print("   variants agree:", float((a == b).mean()))
         else: print("   max |diff| between variants:", float(np.abs(a - b).max()))
 
-if __name__ == "__main__":
+if __name__ == "__main__":  # noqa
     Tf = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     run(C.bl6_laplace(1, 0), 1, Tf)
     run(C.bl6_laplace(1, 0), 64, Tf)
