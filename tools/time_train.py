@@ -1,0 +1,38 @@
+"""dev tool: one training step (forward + backward, fp32 HIP kernels) at the BASELINE cfg4 shape."""
+import sys, os
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R)
+import torch
+from shallow_wavenet_amd import config as C
+from shallow_wavenet_amd.nets import cswnv_shift1 as mc
+from shallow_wavenet_amd.synth import synth_state_dict, synth_aux
+
+B, Tf = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8, 150)
+for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True).items()})
+    m.cuda().train()
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    T = Tf * cfg.U
+    audio = (torch.rand(B, 1, T - cfg.seg, generator=torch.Generator().manual_seed(2)) * 1.8 - 0.9).cuda()
+    Tp = T - 2 * cfg.seg + 1
+    tgt = (torch.rand(B, Tp, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9).cuda()
+
+    def step():
+        res = m(aux, audio)
+        mu, b, log_b = res[0].reshape(B, Tp), res[1].reshape(B, Tp), res[2].reshape(B, Tp)
+        loss = mc.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
+        for p in m.parameters():
+            p.grad = None
+        loss.backward()
+        return loss
+
+    for _ in range(2): step()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 5
+    for _ in range(n): step()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    macs_fwd = (cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.S * cfg.S + cfg.n_out * cfg.S) * B * Tp
+    print(f"{nm} B={B} Tf={Tf}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
