@@ -327,12 +327,12 @@ extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const floa
     DecArgs a;
     int rc = swn_make_geom(d, &a.g);
     if (rc < 0) return rc;
-    if (!packed || !cond || !noise || !out || batch < 1 || n_frames < 1 || n_steps < 0)
-        return SWN_E_BADARG;
+    if (batch < 1 || n_frames < 1 || n_steps < 0) return SWN_E_BADARG;
+    if (n_steps == 0) return SWN_OK;                       // nothing to generate (empty buffers may be null)
+    if (!packed || !cond || !noise || !out) return SWN_E_BADARG;
     if ((long)n_steps * a.g.seg > (long)n_frames * a.g.U) return SWN_E_BADARG;   // conditioning too short
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls
-    if (n_steps == 0) return SWN_OK;
     if (variant == 0 || variant == 2) {
         rc = swn_decode_bl6_try(d, packed, cond, batch, n_frames, n_steps, noise, forced, out, heads, stream_);
         if (rc != SWN_E_UNSUPPORTED || variant == 2) return rc;

@@ -1,0 +1,95 @@
+"""GPU: edge cases and error behaviour of the C-ABI entry points (empty / minimal / ragged inputs,
+argument validation, determinism)."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from shallow_wavenet_amd import _lib, config as C
+from shallow_wavenet_amd.runtime import HipNet
+from shallow_wavenet_amd.synth import synth_aux, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _net(cfg, seed=4):
+    return HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=seed, flavor="trained"), "cuda:0")
+
+
+def test_zero_steps_is_a_no_op(gpu_ok):
+    cfg = C.bl6_laplace(1, 0)
+    net = _net(cfg)
+    out, heads = net.decode(torch.from_numpy(synth_aux(cfg, 2, 3)), 0, torch.empty(2, 0, 1), want_heads=True)
+    assert out.shape == (2, 0) and heads.shape == (2, 0, 2)
+
+
+def test_single_frame_single_step(gpu_ok):
+    for cfg in (C.bl6_laplace(1, 0), C.tiny("laplace", 5, 4), C.tiny("softmax")):
+        net = _net(cfg)
+        soft = cfg.kind == "softmax"
+        w = cfg.n_quantize if soft else cfg.seg
+        noise = torch.full((1, 1, w), 0.25)
+        out, _ = net.decode(torch.from_numpy(synth_aux(cfg, 1, 1)), 1, noise)
+        assert out.shape == (1, 1 if soft else cfg.seg)
+        if not soft:
+            assert torch.isfinite(out).all() and float(out.abs().max()) <= 1.0
+
+
+def test_more_steps_than_conditioning_is_rejected(gpu_ok):
+    cfg = C.bl6_laplace(1, 0)
+    net = _net(cfg)
+    n = 2 * cfg.U + 1
+    with pytest.raises(RuntimeError, match="bad argument"):
+        net.decode(torch.from_numpy(synth_aux(cfg, 1, 2)), n, torch.zeros(1, n, 1))
+
+
+def test_wrong_shapes_raise(gpu_ok):
+    cfg = C.bl6_laplace(1, 0)
+    net = _net(cfg)
+    with pytest.raises(RuntimeError, match="channels"):
+        net.frontend(torch.zeros(1, cfg.n_aux + 1, 4))
+    with pytest.raises(RuntimeError, match="noise shape"):
+        net.decode(torch.from_numpy(synth_aux(cfg, 1, 2)), 10, torch.zeros(1, 11, 1))
+    with pytest.raises(RuntimeError, match="audio has"):
+        net.forward(torch.from_numpy(synth_aux(cfg, 1, 2)), torch.zeros(1, 1, 7))
+    # null pointers at the ABI level
+    d = _lib.desc_from_cfg(cfg)
+    rc = _lib.lib().swn_frontend(ctypes.byref(d), None, None, 1, 2, None, None, None)
+    assert rc == -2
+
+
+def test_decode_is_deterministic_and_batch_independent(gpu_ok):
+    """no cross-utterance dependency: an utterance decodes to the same samples alone or in a batch of 5
+    (same features, same noise rows) and twice in a row (bit-exact)."""
+    cfg = C.bl6_laplace(1, 0)
+    net = _net(cfg)
+    aux = torch.from_numpy(synth_aux(cfg, 5, 3))
+    n = 3 * cfg.U
+    noise = torch.empty(5, n, 1).uniform_(-0.4999, 0.5, generator=torch.Generator().manual_seed(3))
+    a, _ = net.decode(aux, n, noise)
+    b, _ = net.decode(aux, n, noise)
+    assert torch.equal(a, b)
+    solo, _ = net.decode(aux[2:3], n, noise[2:3])
+    assert torch.equal(solo[0], a[2])
+
+
+def test_variants_agree_on_a_ragged_batch(gpu_ok):
+    cfg = C.bl6_laplace(5, 4)
+    net = _net(cfg)
+    aux = synth_aux(cfg, 3, 4)
+    aux[1, :, 3:] = 0
+    aux[2, :, 2:] = 0
+    n = 4 * cfg.U // cfg.seg
+    noise = torch.empty(3, n, cfg.seg).uniform_(-0.4999, 0.5, generator=torch.Generator().manual_seed(5))
+    g, _ = net.decode(torch.from_numpy(aux), n, noise, variant=1)
+    f, _ = net.decode(torch.from_numpy(aux), n, noise, variant=2)
+    assert float((g - f).abs().max()) <= 1e-5
+
+
+def test_forward_minimal_length(gpu_ok):
+    cfg = C.tiny("laplace", 2, 4)
+    net = _net(cfg)
+    raw, hs = net.forward(torch.from_numpy(synth_aux(cfg, 2, 1)), torch.zeros(2, 1, cfg.U - cfg.seg), want_hidden=True)
+    assert raw.shape == (2, cfg.n_out, cfg.U - 2 * cfg.seg + 1) and torch.isfinite(raw).all()
+    assert hs.shape == (2, cfg.L + 1, cfg.H, cfg.U - 2 * cfg.seg + 1)
