@@ -315,10 +315,17 @@ extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, co
                                   int batch, int n_frames, int n_steps, const float* noise,
                                   const void* forced, void* out, float* heads, void* stream);
 
+// defined in swn_decode_stepped.hip
+extern "C" size_t swn_decode_stepped_state_floats(const swn_net_desc* d, int batch);
+extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
+                                  int n_steps, const float* noise, const void* forced, float* state, void* out,
+                                  float* heads, void* stream);
+
 extern "C" size_t swn_decode_state_floats(const swn_net_desc* d, int batch) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1) return 0;
     int off[SWN_MAXL], len[SWN_MAXL];
-    return (size_t)ring_plan(g, off, len) * batch;
+    const size_t a = (size_t)ring_plan(g, off, len) * batch, b = swn_decode_stepped_state_floats(d, batch);
+    return a > b ? a : b;                                  // large enough for every kernel variant
 }
 
 extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const float* cond, int batch,
@@ -338,6 +345,12 @@ extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const floa
         if (rc != SWN_E_UNSUPPORTED || variant == 2) return rc;
     }
     if (!state) return SWN_E_BADARG;
+    // large geometries (REF6: MBs of weights per step) run one launch per phase over many CUs
+    const bool big = (size_t)a.g.L * 2 * a.g.H * a.g.K * a.g.Hp >= (size_t)256 * 1024;
+    if (variant == 3 || (variant == 0 && big)) {
+        rc = swn_decode_stepped(d, packed, cond, batch, n_frames, n_steps, noise, forced, state, out, heads, stream_);
+        if (rc != SWN_E_UNSUPPORTED || variant == 3) return rc;
+    }
     swn_make_layout(&a.g, &a.y);
     a.packed = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state;
     a.out = out; a.heads = heads; a.B = batch; a.Tf = n_frames; a.n_steps = n_steps;

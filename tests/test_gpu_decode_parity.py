@@ -31,7 +31,8 @@ def _net(cfg, d):
 
 
 def _variants(cfg):
-    return [1, 0]
+    """1 generic persistent, 3 stepped multi-launch, 0 auto (BL6 fast kernel / stepped for REF6)"""
+    return [1, 3, 0]
 
 
 @pytest.mark.parametrize("name", LAP)

@@ -4,7 +4,7 @@ _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.inser
 from shallow_wavenet_amd import config as C
 import time_decode as T
 Tf = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-T.run(C.ref6_laplace(1, 4), 1, Tf, variants=(1,), reps=2)
-T.run(C.ref6_laplace(5, 4), 1, Tf, variants=(1,), reps=2)
-T.run(C.ref6_softmax(), 1, Tf, variants=(1,), reps=2)
-T.run(C.ref6_laplace(1, 4), 64, Tf, variants=(1,), reps=1)
+T.run(C.ref6_laplace(1, 4), 1, Tf, variants=(1, 3), reps=2)
+T.run(C.ref6_laplace(5, 4), 1, Tf, variants=(1, 3), reps=2)
+T.run(C.ref6_softmax(), 1, Tf, variants=(1, 3), reps=2)
+T.run(C.ref6_laplace(1, 4), 64, Tf, variants=(3,), reps=1)
