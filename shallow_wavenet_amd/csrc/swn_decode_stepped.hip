@@ -5,16 +5,18 @@
 // (MI355X_MICROARCH.md price list) - about what a dependent kernel boundary costs (1.45 us).  So every
 // phase of a step is its OWN launch, spread over many CUs that each read a slice of the weight rows from
 // L2 / Infinity Cache:
-//     step_in      h0 = softsign(causal(lift(S)))                    1 workgroup / utterance
-//     step_layer   x L : rows of one dilated conv + fused gate        8 channel pairs / workgroup
-//     rowvec       skip (all out_skip 1x1s as one mat-vec), out_1    8 rows / workgroup
-//     step_tail    out_2 + sampling + history update                 1 workgroup / utterance
-// L+4 launches per generated step, no spinning, no inter-workgroup protocol: the stream order is the
-// dependency chain (cswnv_shift1.py:348-402).  State (history rings, hcat, skip, out_1, sample window,
-// iteration counter) lives in the caller's scratch buffer; the math and the ring layout are those of
-// the generic persistent kernel (swn_decode.hip), so the two are interchangeable.
+//     step_layer   x L : rows of one dilated conv + fused gate        one wave per channel pair
+//     rowvec       skip (all out_skip 1x1s as one mat-vec), out_1    one wave per row
+//     step_tail    out_2 + sampling + history update + the NEXT step's input layer   1 workgroup / utterance
+// L+3 launches per generated step, no spinning, no inter-workgroup protocol: the stream order is the
+// dependency chain (cswnv_shift1.py:348-402).  The iteration index is a launch argument (no dependent
+// load at kernel entry); measured: the chain is bound by the L2 round trips inside each launch, not by
+// host launch cost (hipGraph replay of the same chain ran at the same speed, so it is not used).
+// State (history rings, hcat, skip, out_1, sample window) lives in the caller's scratch buffer; the math
+// and the ring layout are those of the generic persistent kernel (swn_decode.hip).
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
+#include <cstdlib>
 
 namespace {
 
@@ -30,6 +32,11 @@ struct StArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ int pmod(int r, int m) { int t = r % m; return t < 0 ? t + m : t; }
+__device__ __forceinline__ float sum64(float v) {
+    v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 1, 64);
+    return v;
+}
 __device__ __forceinline__ float sum32(float v) {
     v += __shfl_xor(v, 16, 32); v += __shfl_xor(v, 8, 32); v += __shfl_xor(v, 4, 32);
     v += __shfl_xor(v, 2, 32);  v += __shfl_xor(v, 1, 32);
@@ -44,22 +51,17 @@ __device__ __forceinline__ Iter iter_of(const StArgs& a, int it) {
     return r;
 }
 
-// ---- step_in: advance the counter, input layer -> ring 0 ----------------------------------------
+// ---- input layer of iteration `it` -> ring 0 (device function: own launch in the prologue, fused into
+//      the tail of the previous step during generation)
 template <int KIND>
-__global__ __launch_bounds__(256) void step_in_kernel(const StArgs a) {
+__device__ __forceinline__ void input_layer(const StArgs& a, float* st, const int it, const int tid, const int nthreads) {
     const SwnGeom& g = a.g;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    float* st = a.state + (size_t)b * a.stride;
-    int* cnt = reinterpret_cast<int*>(st + a.o_cnt);         // [0] next iteration, [1] current iteration
-    const int it = cnt[0];
-    __syncthreads();
-    if (tid == 0) { cnt[1] = it; cnt[0] = it + 1; }
     const Iter r = iter_of(a, it);
     const float* P = a.P;
     const float* shist = st + a.o_hist;
     const int* ihist = reinterpret_cast<const int*>(shist);
     const int H = g.H, K = g.K, seg = g.seg, WN = a.WN;
-    for (int e = tid; e < H * r.np; e += 256) {
+    for (int e = tid; e < H * r.np; e += nthreads) {
         const int j = e / H, o = e - j * H, q = r.q0 + j;
         float acc = P[a.y.cb + o];
         for (int k = 0; k < K; ++k) {
@@ -80,12 +82,19 @@ __global__ __launch_bounds__(256) void step_in_kernel(const StArgs a) {
     }
 }
 
-// ---- step_layer: 8 channel pairs per workgroup, 32 lanes per pair, weights kept in registers ------
-template <int NI, int KIND>       // NI = ceil(K*Hp / 128): float4 pieces per lane and row
-__global__ __launch_bounds__(256) void step_layer_kernel(const StArgs a, const int l) {
+template <int KIND>
+__global__ __launch_bounds__(256) void step_in_kernel(const StArgs a, const int it) {
+    input_layer<KIND>(a, a.state + (size_t)blockIdx.x * a.stride, it, threadIdx.x, 256);
+}
+
+// ---- step_layer: ONE wave per channel pair (gate row + candidate row), weights kept in registers.
+//      Kernel boundaries invalidate the per-XCD L2s, so every launch re-fetches its weight rows from the
+//      Infinity Cache at ~30 GB/s per CU: H workgroups of 64 lanes keep each CU's share at ~10 KB.
+template <int NI, int KIND, int BT>   // NI = ceil(K*Hp / 256): float4 pieces per lane and row; BT = utterances per tile
+__global__ __launch_bounds__(64) void step_layer_kernel(const StArgs a, const int l, const int it) {
     const SwnGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
-    const int o = blockIdx.x * 8 + grp;
+    const int lane = threadIdx.x;
+    const int o = blockIdx.x;
     const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg, KH = K * Hp;
     const bool live = o < H;
     const float* P = a.P;
@@ -94,94 +103,148 @@ __global__ __launch_bounds__(256) void step_layer_kernel(const StArgs a, const i
         const float* rz = P + a.y.wd + ((size_t)l * H2 + (live ? o : 0)) * KH;
         const float* rc = rz + (size_t)H * KH;
 #pragma unroll
-        for (int it = 0; it < NI; ++it) {
-            const int idx = it * 128 + lane * 4;
+        for (int pc = 0; pc < NI; ++pc) {
+            const int idx = pc * 256 + lane * 4;
             const bool ok = live && idx < KH;
-            wz[it] = ok ? *reinterpret_cast<const float4*>(rz + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wc[it] = ok ? *reinterpret_cast<const float4*>(rc + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wz[pc] = ok ? *reinterpret_cast<const float4*>(rz + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wc[pc] = ok ? *reinterpret_cast<const float4*>(rc + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     }
     const int dil = g.dil[l], R = a.ring_len[l];
-    for (int b = blockIdx.y * 8; b < a.B && b < blockIdx.y * 8 + 8; ++b) {
-        float* st = a.state + (size_t)b * a.stride;
-        const Iter r = iter_of(a, reinterpret_cast<const int*>(st + a.o_cnt)[1]);
-        const float* ring = st + a.ring_off[l];
-        for (int j = 0; j < r.np; ++j) {
-            const int q = r.q0 + j;
-            float az = 0.f, ac = 0.f;
+    const Iter r = iter_of(a, it);
+    const int b0 = blockIdx.y * BT;
+    const int nb = a.B - b0 < BT ? a.B - b0 : BT;              // utterances of this tile, processed CONCURRENTLY:
+    for (int j = 0; j < r.np; ++j) {                          // lane u finishes utterance b0+u
+        const int q = r.q0 + j;
+        // epilogue operands first (independent of the mat-vec): their latency hides under it
+        float gz = 0.f, gc = 0.f, bdz = 0.f, bdc = 0.f, hp = 0.f;
+        if (lane < nb && live) {
+            const int b = b0 + lane;
+            const float* st = a.state + (size_t)b * a.stride;
+            gz = P[a.y.bx + (size_t)l * H2 + o]; gc = P[a.y.bx + (size_t)l * H2 + H + o];
+            bdz = P[a.y.bd + (size_t)l * H2 + o]; bdc = P[a.y.bd + (size_t)l * H2 + H + o];
+            hp = st[a.ring_off[l] + (size_t)pmod(q, R) * Hp + o];
+            const float* condb = a.cond + (size_t)b * a.Tf * g.N;
+            for (int s = 0; s < seg; ++s) {
+                int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
+                int f = tt / g.U; const int jj = tt - f * g.U;
+                f = f < a.Tf ? f : a.Tf - 1;
+                const float w = P[a.y.wup + jj];
+                const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+                gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
+            }
+            if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
+                const int* ihist = reinterpret_cast<const int*>(st + a.o_hist);
+                const int qe = r.gen ? g.rf + r.i : g.rf;
+                const int idx = r.gen ? ihist[q - qe + a.WN - 1] : g.Q / 2;
+                const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
+                gz += wa[o]; gc += wa[H + o];
+            }
+        }
+        float az[BT], ac[BT];
 #pragma unroll
-            for (int it = 0; it < NI; ++it) {
-                const int idx = it * 128 + lane * 4;
-                if (idx < KH) {
-                    const int tap = idx / Hp, i = idx - tap * Hp;
-                    const float4 x = *reinterpret_cast<const float4*>(ring + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i);
-                    az = fmaf(wz[it].x, x.x, az); az = fmaf(wz[it].y, x.y, az); az = fmaf(wz[it].z, x.z, az); az = fmaf(wz[it].w, x.w, az);
-                    ac = fmaf(wc[it].x, x.x, ac); ac = fmaf(wc[it].y, x.y, ac); ac = fmaf(wc[it].z, x.z, ac); ac = fmaf(wc[it].w, x.w, ac);
+        for (int u = 0; u < BT; ++u) { az[u] = 0.f; ac[u] = 0.f; }
+#pragma unroll
+        for (int pc = 0; pc < NI; ++pc) {
+            const int idx = pc * 256 + lane * 4;
+            if (idx < KH) {
+                const int tap = idx / Hp, i = idx - tap * Hp;
+                const size_t xo = a.ring_off[l] + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i;
+#pragma unroll
+                for (int u = 0; u < BT; ++u) {
+                    if (u < nb) {
+                        const float4 x = *reinterpret_cast<const float4*>(a.state + (size_t)(b0 + u) * a.stride + xo);
+                        az[u] = fmaf(wz[pc].x, x.x, az[u]); az[u] = fmaf(wz[pc].y, x.y, az[u]);
+                        az[u] = fmaf(wz[pc].z, x.z, az[u]); az[u] = fmaf(wz[pc].w, x.w, az[u]);
+                        ac[u] = fmaf(wc[pc].x, x.x, ac[u]); ac[u] = fmaf(wc[pc].y, x.y, ac[u]);
+                        ac[u] = fmaf(wc[pc].z, x.z, ac[u]); ac[u] = fmaf(wc[pc].w, x.w, ac[u]);
+                    }
                 }
             }
-            az = sum32(az); ac = sum32(ac);
-            if (lane == 0 && live) {
-                float gz = P[a.y.bx + (size_t)l * H2 + o], gc = P[a.y.bx + (size_t)l * H2 + H + o];
-                const float* condb = a.cond + (size_t)b * a.Tf * g.N;
-                for (int s = 0; s < seg; ++s) {
-                    int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
-                    int f = tt / g.U; const int jj = tt - f * g.U;
-                    f = f < a.Tf ? f : a.Tf - 1;
-                    const float w = P[a.y.wup + jj];
-                    const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
-                    gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
-                }
-                if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
-                    const int* ihist = reinterpret_cast<const int*>(st + a.o_hist);
-                    const int qe = r.gen ? g.rf + r.i : g.rf;
-                    const int idx = r.gen ? ihist[q - qe + a.WN - 1] : g.Q / 2;
-                    const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
-                    gz += wa[o]; gc += wa[H + o];
-                }
-                const float z = sigm(gz * (az + P[a.y.bd + (size_t)l * H2 + o]));
-                const float c = tanhf(gc * (ac + P[a.y.bd + (size_t)l * H2 + H + o]));
-                const float hn = (1.f - z) * c + z * ring[(size_t)pmod(q, R) * Hp + o];
-                if (l + 1 < g.L) st[a.ring_off[l + 1] + pmod(q, a.ring_len[l + 1]) * Hp + o] = hn;
-                if (j == r.np - 1) st[a.o_hcat + l * Hp + o] = hn;
+        }
+        float myz = 0.f, myc = 0.f;
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            if (u < nb) {
+                const float sz = sum64(az[u]), sc = sum64(ac[u]);
+                if (lane == u) { myz = sz; myc = sc; }
             }
+        }
+        if (lane < nb && live) {
+            float* st = a.state + (size_t)(b0 + lane) * a.stride;
+            const float z = sigm(gz * (myz + bdz));
+            const float c = tanhf(gc * (myc + bdc));
+            const float hn = (1.f - z) * c + z * hp;
+            if (l + 1 < g.L) st[a.ring_off[l + 1] + pmod(q, a.ring_len[l + 1]) * Hp + o] = hn;
+            if (j == r.np - 1) st[a.o_hcat + l * Hp + o] = hn;
         }
     }
 }
 
-// ---- rowvec: y[b][row] = act(bias[row] + W[row][:] . x[b][:]), 8 rows / workgroup, 32 lanes / row --
-__global__ __launch_bounds__(256) void rowvec_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
-                                                     int ni, int x_off, int y_off, int relu) {
-    const int tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
-    const int row = blockIdx.x * 8 + grp;
-    const bool live = row < rows;
-    const float* wr = a.P + w_off + (size_t)(live ? row : 0) * ldw;
-    const float bias = live ? a.P[b_off + row] : 0.f;
-    for (int b = blockIdx.y * 8; b < a.B && b < blockIdx.y * 8 + 8; ++b) {
-        float* st = a.state + (size_t)b * a.stride;
-        const float* x = st + x_off;
-        float acc = 0.f;
-        for (int idx = lane * 4; idx < ni; idx += 128) {
-            const float4 w = live ? *reinterpret_cast<const float4*>(wr + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 xv = *reinterpret_cast<const float4*>(x + idx);
-            acc = fmaf(w.x, xv.x, acc); acc = fmaf(w.y, xv.y, acc); acc = fmaf(w.z, xv.z, acc); acc = fmaf(w.w, xv.w, acc);
+// ---- rowvec: y[b][row] = act(bias[row] + W[row][:] . x[b][:]), ONE wave per row -------------------------
+template <int BT>
+__global__ __launch_bounds__(64) void rowvec_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
+                                                    int ni, int x_off, int y_off, int relu) {
+    const int lane = threadIdx.x, row = blockIdx.x;
+    const float* wr = a.P + w_off + (size_t)row * ldw;
+    const float bias = a.P[b_off + row];
+    const int b0 = blockIdx.y * BT;
+    const int nb = a.B - b0 < BT ? a.B - b0 : BT;              // utterances of this tile, processed concurrently
+    float acc[BT];
+#pragma unroll
+    for (int u = 0; u < BT; ++u) acc[u] = 0.f;
+    for (int idx = lane * 4; idx < ni; idx += 256) {
+        const float4 w = *reinterpret_cast<const float4*>(wr + idx);
+#pragma unroll
+        for (int u = 0; u < BT; ++u) {
+            if (u < nb) {
+                const float4 xv = *reinterpret_cast<const float4*>(a.state + (size_t)(b0 + u) * a.stride + x_off + idx);
+                acc[u] = fmaf(w.x, xv.x, acc[u]); acc[u] = fmaf(w.y, xv.y, acc[u]);
+                acc[u] = fmaf(w.z, xv.z, acc[u]); acc[u] = fmaf(w.w, xv.w, acc[u]);
+            }
         }
-        acc = sum32(acc);
-        if (lane == 0 && live) { const float v = acc + bias; st[y_off + row] = relu ? fmaxf(v, 0.f) : v; }
+    }
+    float mine = 0.f;
+#pragma unroll
+    for (int u = 0; u < BT; ++u) {
+        if (u < nb) { const float sv = sum64(acc[u]); if (lane == u) mine = sv; }
+    }
+    if (lane < nb) {
+        const float v = mine + bias;
+        a.state[(size_t)(b0 + lane) * a.stride + y_off + row] = relu ? fmaxf(v, 0.f) : v;
     }
 }
 
-// ---- step_tail: sampling from the head outputs o2v, history update (one workgroup / utterance) -----
+// ---- step_tail: out_2, sampling, history update, then the input layer of the next step ---------------
 template <int KIND>
-__global__ __launch_bounds__(64) void step_tail_kernel(const StArgs a) {
+__global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const int it) {
+    __shared__ float o2v[4096 + 16];
     const SwnGeom& g = a.g;
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
     float* st = a.state + (size_t)b * a.stride;
-    const int it = reinterpret_cast<const int*>(st + a.o_cnt)[1];
     const int i = it - a.n_pro, seg = g.seg, WN = a.WN;
-    const float* o2v = st + a.o_o2;
+    // out_2 rows: 8 rows per pass, 32 lanes per row
+    {
+        const float* x = st + a.o_o1;
+        for (int r0 = 0; r0 < g.NO; r0 += 8) {
+            const int row = r0 + grp;
+            float acc = 0.f;
+            if (row < g.NO) {
+                const float* wr = a.P + a.y.w2 + (size_t)row * g.O1p;
+                for (int idx = lane * 4; idx < g.O1p; idx += 128) {
+                    const float4 w = *reinterpret_cast<const float4*>(wr + idx);
+                    const float4 xv = *reinterpret_cast<const float4*>(x + idx);
+                    acc = fmaf(w.x, xv.x, acc); acc = fmaf(w.y, xv.y, acc); acc = fmaf(w.z, xv.z, acc); acc = fmaf(w.w, xv.w, acc);
+                }
+            }
+            acc = sum32(acc);
+            if (lane == 0 && row < g.NO) o2v[row] = acc + a.P[a.y.b2 + row];
+        }
+    }
+    __syncthreads();
     float* shist = st + a.o_hist;
     int* ihist = reinterpret_cast<int*>(shist);
-    if (a.heads) for (int e = tid; e < g.NO; e += 64) a.heads[((size_t)b * a.n_steps + i) * g.NO + e] = o2v[e];
+    if (a.heads) for (int e = tid; e < g.NO; e += 256) a.heads[((size_t)b * a.n_steps + i) * g.NO + e] = o2v[e];
     if (KIND == SWN_KIND_LAPLACE) {
         if (tid == 0) {
 #pragma clang fp contract(off)
@@ -211,7 +274,7 @@ __global__ __launch_bounds__(64) void step_tail_kernel(const StArgs a) {
             for (int k = 0; k + seg < WN; ++k) shist[k] = shist[k + seg];
             for (int j = 0; j < seg; ++j) shist[WN - seg + j] = fed[j];
         }
-    } else {
+    } else if (tid < 64) {
         // softmax head, dswnv.py:361-369
         const int Q = g.Q;
         const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
@@ -242,6 +305,10 @@ __global__ __launch_bounds__(64) void step_tail_kernel(const StArgs a) {
             ihist[WN - 1] = fd;
         }
     }
+    // the sample window was just updated through global memory by thread 0: make it visible to the
+    // block (same CU), then run the next step's input layer here - one launch less per step
+    __syncthreads();
+    if (i + 1 < a.n_steps) input_layer<KIND>(a, st, it + 1, tid, 256);
 }
 
 // set the sample window seed (softmax: mu-law zero class) after the state was zeroed
@@ -266,13 +333,6 @@ int plan(StArgs& a) {
     return a.stride;
 }
 
-template <int NI>
-void launch_layer(const StArgs& a, int l, hipStream_t st) {
-    dim3 grid((a.g.H + 7) / 8, (a.B + 7) / 8);
-    if (a.g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL((step_layer_kernel<NI, SWN_KIND_LAPLACE>), grid, dim3(256), 0, st, a, l);
-    else hipLaunchKernelGGL((step_layer_kernel<NI, SWN_KIND_SOFTMAX>), grid, dim3(256), 0, st, a, l);
-}
-
 }  // namespace
 
 extern "C" size_t swn_decode_stepped_state_floats(const swn_net_desc* d, int batch) {
@@ -288,8 +348,8 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     int rc = swn_make_geom(d, &a.g);
     if (rc < 0) return rc;
     const SwnGeom& g = a.g;
-    const int ni = (g.K * g.Hp + 127) / 128;
-    if (ni > 14 || g.seg > 16 || g.lpc > 16) return SWN_E_UNSUPPORTED;
+    const int ni = (g.K * g.Hp + 255) / 256;
+    if (ni > 8 || g.seg > 16 || g.lpc > 16 || g.NO > 4096) return SWN_E_UNSUPPORTED;
     swn_make_layout(&a.g, &a.y);
     plan(a);
     a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state; a.out = out; a.heads = heads;
@@ -297,26 +357,50 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     hipStream_t st = (hipStream_t)stream_;
     if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.stride * batch, st) != hipSuccess) return SWN_E_LAUNCH;
     if (g.kind == SWN_KIND_SOFTMAX) hipLaunchKernelGGL(step_seed_kernel, dim3(batch), dim3(64), 0, st, a);
-    const int total = a.n_pro + n_steps;
-    const dim3 bgrid8((unsigned)1, (unsigned)((batch + 7) / 8));
-    for (int it = 0; it < total; ++it) {
-        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_in_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL(step_in_kernel<SWN_KIND_SOFTMAX>, dim3(batch), dim3(256), 0, st, a);
+    // up to 64 utterances: one utterance per workgroup (weights re-read per utterance from the Infinity Cache;
+    // measured faster than sharing: B=8 63 vs 137 us/step, B=64 162 vs 182 us/step on REF6);
+    // otherwise tiles of 8 utterances share one weight fetch and are processed concurrently
+    const char* solo_env = getenv("SWN_STEPPED_SOLO_MAX");      // tuning knob, default from measurements
+    const bool solo = batch <= (solo_env ? atoi(solo_env) : 64);
+    const unsigned by = solo ? (unsigned)batch : (unsigned)((batch + 7) / 8);
+#define SWN_LAYER(NI_, KIND_)                                                                                  \
+    do {                                                                                                        \
+        if (solo) hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 1>), grid, dim3(64), 0, st, a, l, it);      \
+        else hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 8>), grid, dim3(64), 0, st, a, l, it);           \
+    } while (0)
+    auto layers = [&](int it) {
         for (int l = 0; l < g.L; ++l) {
-            if (ni <= 1) launch_layer<1>(a, l, st);
-            else if (ni <= 4) launch_layer<4>(a, l, st);
-            else if (ni <= 11) launch_layer<11>(a, l, st);
-            else launch_layer<14>(a, l, st);
+            dim3 grid(g.H, by);
+            if (g.kind == SWN_KIND_LAPLACE) {
+                if (ni <= 1) SWN_LAYER(1, SWN_KIND_LAPLACE);
+                else if (ni <= 6) SWN_LAYER(6, SWN_KIND_LAPLACE);
+                else SWN_LAYER(8, SWN_KIND_LAPLACE);
+            } else {
+                if (ni <= 1) SWN_LAYER(1, SWN_KIND_SOFTMAX);
+                else if (ni <= 6) SWN_LAYER(6, SWN_KIND_SOFTMAX);
+                else SWN_LAYER(8, SWN_KIND_SOFTMAX);
+            }
         }
+    };
+#undef SWN_LAYER
+    auto rowvec = [&](int rows, size_t w_off, int ldw, size_t b_off, int nin, int x_off, int y_off) {
+        if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, 1);
+        else hipLaunchKernelGGL(rowvec_kernel<8>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, 1);
+    };
+    const int total = a.n_pro + n_steps;
+    for (int it = 0; it < total; ++it) {
+        // prologue positions and the very first generation step launch their own input layer; later steps
+        // get it from the tail of the step before
+        if (it <= a.n_pro) {
+            if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_in_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(256), 0, st, a, it);
+            else hipLaunchKernelGGL(step_in_kernel<SWN_KIND_SOFTMAX>, dim3(batch), dim3(256), 0, st, a, it);
+        }
+        layers(it);
         if (it < a.n_pro) continue;
-        hipLaunchKernelGGL(rowvec_kernel, dim3((g.S + 7) / 8, bgrid8.y), dim3(256), 0, st, a, a.y.wsk, g.L * g.Hp, a.y.bsk,
-                           g.S, g.L * g.Hp, a.o_hcat, a.o_skip, 1);
-        hipLaunchKernelGGL(rowvec_kernel, dim3((g.O1 + 7) / 8, bgrid8.y), dim3(256), 0, st, a, a.y.w1, g.Sp, a.y.b1,
-                           g.O1, g.Sp, a.o_skip, a.o_o1, 1);
-        hipLaunchKernelGGL(rowvec_kernel, dim3((g.NO + 7) / 8, bgrid8.y), dim3(256), 0, st, a, a.y.w2, g.O1p, a.y.b2,
-                           g.NO, g.O1p, a.o_o1, a.o_o2, 0);
-        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(64), 0, st, a);
-        else hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_SOFTMAX>, dim3(batch), dim3(64), 0, st, a);
+        rowvec(g.S, a.y.wsk, g.L * g.Hp, a.y.bsk, g.L * g.Hp, a.o_hcat, a.o_skip);
+        rowvec(g.O1, a.y.w1, g.Sp, a.y.b1, g.Sp, a.o_skip, a.o_o1);
+        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(256), 0, st, a, it);
+        else hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_SOFTMAX>, dim3(batch), dim3(256), 0, st, a, it);
     }
     return swn_launch_status("swn_decode(stepped)");
 }
