@@ -109,24 +109,85 @@ __global__ void pack_wd_kernel(const float* __restrict__ wd, int L, unsigned sho
     dst[e] = f2bf(wd[((size_t)l * 128 + row) * 128 + k]);
 }
 
-struct LayerOps {
-    bf16x8 b[4];        // B fragments: K-steps 0,1 = h(t-dil) channels 0-31 / 32-63, 2,3 = h(t)
-    float4 cz[4], cc[4];// hoisted in_x rows of this lane's 16 channels (gate | candidate), first segment
-    float wu;           // upsampler tap of position t (seg == 1 fast path)
+// Buffer-resource loads: one 32-bit per-lane byte offset per load (an out-of-range offset reads zeros, which is
+// how the causal zero padding and ragged tails are produced) instead of 64-bit address arithmetic per load.
+constexpr unsigned OOB = 0x80000000u;   // host guarantees every buffer is smaller than 2 GiB
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 buf_ld_bf8(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float4 buf_ld_f4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0));
+}
+__device__ __forceinline__ float buf_ld_f1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+
+struct BFrag { bf16x8 b[4]; };          // B fragments: K-steps 0,1 = h(t-dil) channels 0-31 / 32-63, 2,3 = h(t)
+struct CondOps {
+    float4 cz[4], cc[4];                // hoisted in_x rows of this lane's 16 channels (gate | candidate)
+    float wu;                           // upsampler tap of position t
 };
-constexpr int NSUB = 2;  // 16-position chunks handled per loop iteration: twice the bytes in flight per wave
+constexpr int NSLOT = 8;                // B-fragment ring (AccVGPRs): chunk k+7 is fetched while chunk k is computed:
+                                        // ~7 KB of HBM reads in flight per wave, what the latency-bandwidth product needs
+constexpr float K_SIG = -1.44269504f;   // sigmoid(x) = 1 / (1 + 2^(K_SIG x))
+constexpr float K_TANH = 2.88539008f;   // tanh(x)    = 1 - 2 / (1 + 2^(K_TANH x))
+
+
+// The 32 MFMAs of one chunk, written as asm so that the register classes are what the loop needs: the
+// layer matrix (A, 128 registers) and the tap-0 B fragments live in AccVGPRs, which MFMA reads directly,
+// while the accumulators are produced in architectural VGPRs where the epilogue's vector ALU can use them.
+// (Left to the allocator, ~100 v_accvgpr_read copies per chunk were issued - a quarter of the loop.)
+// K-step-major order keeps dependent MFMAs 8 instructions apart; the first K-step takes the dil_h bias as
+// its C operand.  The compiler's hazard recognizer cannot see through asm, so the blocks carry their own
+// wait states: a leading s_nop for an operand a vector-ALU copy may have written just before, a trailing
+// s_nop 15 for the MFMA-result -> VALU-read hazard (8-pass XDL op: 11 required).  Fragments the epilogue
+// also reads with the vector ALU (the tap-1 rows, for the highway term) are taken from VGPRs as loaded.
+#define SWN_MF "v_mfma_f32_16x16x32_bf16 "
+template <class BT>
+__device__ __forceinline__ void mfma_first(f32x4 (&acc)[8], const bf16x8 (&A)[8][4], const BT& b, const f32x4 (&c)[8]) {
+    asm("s_nop 3\n\t" SWN_MF "%0, %8, %16, %17\n\t" SWN_MF "%1, %9, %16, %18\n\t" SWN_MF "%2, %10, %16, %19\n\t"
+        SWN_MF "%3, %11, %16, %20\n\t" SWN_MF "%4, %12, %16, %21\n\t" SWN_MF "%5, %13, %16, %22\n\t"
+        SWN_MF "%6, %14, %16, %23\n\t" SWN_MF "%7, %15, %16, %24"
+        : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3]), "=&v"(acc[4]), "=&v"(acc[5]), "=&v"(acc[6]), "=&v"(acc[7])
+        : "a"(A[0][0]), "a"(A[1][0]), "a"(A[2][0]), "a"(A[3][0]), "a"(A[4][0]), "a"(A[5][0]), "a"(A[6][0]), "a"(A[7][0]),
+          "a"(b), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]), "v"(c[4]), "v"(c[5]), "v"(c[6]), "v"(c[7]));
+}
+template <int KS, bool TAIL, bool B_ACC>
+__device__ __forceinline__ void mfma_next(f32x4 (&acc)[8], const bf16x8 (&A)[8][4], const bf16x8& b) {
+#define SWN_MF8 SWN_MF "%0, %8, %16, %0\n\t" SWN_MF "%1, %9, %16, %1\n\t" SWN_MF "%2, %10, %16, %2\n\t" \
+                SWN_MF "%3, %11, %16, %3\n\t" SWN_MF "%4, %12, %16, %4\n\t" SWN_MF "%5, %13, %16, %5\n\t" \
+                SWN_MF "%6, %14, %16, %6\n\t" SWN_MF "%7, %15, %16, %7"
+#define SWN_MF_OPS(BC)                                                                                          \
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]) \
+        : "a"(A[0][KS]), "a"(A[1][KS]), "a"(A[2][KS]), "a"(A[3][KS]), "a"(A[4][KS]), "a"(A[5][KS]), "a"(A[6][KS]),      \
+          "a"(A[7][KS]), BC(b)
+    if (TAIL && B_ACC) asm("s_nop 3\n\t" SWN_MF8 "\n\ts_nop 15" SWN_MF_OPS("a"));
+    else if (TAIL) asm("s_nop 3\n\t" SWN_MF8 "\n\ts_nop 15" SWN_MF_OPS("v"));
+    else if (B_ACC) asm("s_nop 3\n\t" SWN_MF8 SWN_MF_OPS("a"));
+    else asm("s_nop 3\n\t" SWN_MF8 SWN_MF_OPS("v"));
+#undef SWN_MF_OPS
+#undef SWN_MF8
+}
+#undef SWN_MF
 
 // ONE wave owns all 128 rows of a 16-position chunk (A fragments of the whole layer matrix = 128
-// VGPRs, resident; one wave per SIMD with the full 512-entry register file), so every B fragment is
-// loaded exactly once; the four waves of a workgroup walk different chunks.  Measured alternatives
-// (4 waves sharing a chunk, or 2 waves each owning half the channels at 2 waves/SIMD) were 1.5-1.7x
-// slower: the vector-memory path, not MFMA, is what this kernel saturates.
+// registers, resident; one wave per SIMD with the full 512-entry register file), so every B fragment is
+// loaded exactly once; the four waves of a workgroup walk different chunks and never synchronise.
+// The loop is bound by vector-ALU issue (the gate epilogue), not by MFMA or HBM, so everything around
+// the epilogue is kept off the vector ALU: chunk arithmetic is scalar, addresses are 32-bit buffer
+// offsets, the sigmoid/tanh scale factors are folded into the conditioning constants, and saturation
+// needs no clamps (2^x -> inf -> rcp -> 0 gives the exact limits).
+template <bool FAST>   // FAST: seg == 1 and U >= 16, conditioning rows prefetched through the buffer path
 __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, const int l, const int dil, const int n_chunks) {
-    __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | bx[128] of this layer
+    __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | prescaled bx[128] of this layer
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);          // wave-uniform -> scalar chunk arithmetic
     const int n = lane & 15, g = lane >> 4;
-    cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid] : a.P[a.y.bx + (size_t)l * 128 + tid - 128];
+    cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid]
+                         : a.P[a.y.bx + (size_t)l * 128 + tid - 128] * (tid < 192 ? K_SIG : K_TANH);
     bf16x8 A[8][4];
     {
         const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
@@ -137,107 +198,288 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
     }
     __syncthreads();
     const size_t lstride = (size_t)a.B * a.Tp * H;
-    const unsigned short* hprev = a.hs + (size_t)l * lstride;
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
+    const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.P + a.y.wup, (size_t)a.U * 4);
     unsigned short* hnext = a.hs + (size_t)(l + 1) * lstride;
     const int chunks_per_b = (a.Tp + 15) / 16;
+    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_c = (unsigned)(8 * g) * 4u;
+    const unsigned dil_bytes = (unsigned)dil * H * 2u;
 
-    auto fetch = [&](int c, LayerOps& op) {                          // c is wave-uniform: scalar divisions
+    auto fetch_b = [&](int c, BFrag& f) {                            // c is wave-uniform
+        c = c < n_chunks ? c : n_chunks - 1;
         const int b = c / chunks_per_b, t0 = (c - b * chunks_per_b) * 16, t = t0 + n;
-        const unsigned short* hb = hprev + (size_t)b * a.Tp * H;
-        const bool ok = t < a.Tp;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const int ts = t - (ks < 2 ? dil : 0);
-            op.b[ks] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-            if (ok && ts >= 0) op.b[ks] = *reinterpret_cast<const bf16x8*>(hb + (size_t)ts * H + 32 * (ks & 1) + 8 * g);
-        }
+        const unsigned base = (unsigned)(b * a.Tp + t0) * (H * 2u) + lane_h;
+        const unsigned o1 = t < a.Tp ? base : OOB;
+        const unsigned o0 = (t < a.Tp && t >= dil) ? base - dil_bytes : OOB;
+        f.b[0] = buf_ld_bf8(rh, o0); f.b[1] = buf_ld_bf8(rh, o0 + 64u);
+        f.b[2] = buf_ld_bf8(rh, o1); f.b[3] = buf_ld_bf8(rh, o1 + 64u);
+    };
+    auto fetch_c = [&](int c, CondOps& k) {                          // seg == 1 conditioning of chunk c
+        c = c < n_chunks ? c : n_chunks - 1;
+        const int b = c / chunks_per_b, t0 = (c - b * chunks_per_b) * 16;
         const int tt0 = t0 + a.coff;
-        int f = tt0 / a.U, jj = tt0 - f * a.U + n;                   // scalar division, per-lane carry
-        if (jj >= a.U) { jj -= a.U; f += 1; }
-        f = f < a.Tf ? f : a.Tf - 1;
-        op.wu = a.P[a.y.wup + jj];
-        const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)l * a.seg * 128;
+        int f0 = tt0 / a.U;                                          // scalar division
+        const int j0 = tt0 - f0 * a.U;
+        int jj = j0 + n, up = 0;
+        if (jj >= a.U) { jj -= a.U; up = 1; }                        // U >= 16: at most one frame boundary inside a chunk
+        const int last = a.Tf - 1;
+        int f = f0 + up; f = f < last ? f : last;
+        f0 = f0 < last ? f0 : last;
+        const unsigned rowb = (unsigned)((b * a.Tf + f0) * a.N + l * 128) * 4u + lane_c;
+        const unsigned off = rowb + (unsigned)(f - f0) * (unsigned)(a.N * 4);
+        k.wu = buf_ld_f1(ru, (unsigned)jj * 4u);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {              // q: channel group (q>>1)*32 + 8g + 4*(q&1)
-            op.cz[q] = *reinterpret_cast<const float4*>(cr + 32 * (q >> 1) + 8 * g + 4 * (q & 1));
-            op.cc[q] = *reinterpret_cast<const float4*>(cr + H + 32 * (q >> 1) + 8 * g + 4 * (q & 1));
+            k.cz[q] = buf_ld_f4(rc, off + (unsigned)(32 * (q >> 1) + 4 * (q & 1)) * 4u);
+            k.cc[q] = buf_ld_f4(rc, off + (unsigned)(H + 32 * (q >> 1) + 4 * (q & 1)) * 4u);
         }
     };
 
-    const int stride = gridDim.x * 4 * NSUB;                         // every wave walks its own chunk sequence
-    int c0 = (blockIdx.x * 4 + w) * NSUB;
-    if (c0 >= n_chunks) return;
-    LayerOps curs[NSUB], nxts[NSUB];
+    // per-lane epilogue constants of its 16 channels stay in registers (LDS reads inside the epilogue stalled it)
+    f32x4 kbd[8];                      // dil_h bias of accumulator tile mt: the C operand of its first MFMA
+    float4 kbxz[4], kbxc[4];
 #pragma unroll
-    for (int u = 0; u < NSUB; ++u) fetch(c0 + u < n_chunks ? c0 + u : n_chunks - 1, curs[u]);
-    for (; c0 < n_chunks; c0 += stride) {
-        const int cn0 = c0 + stride;
-        if (cn0 < n_chunks) {
+    for (int m = 0; m < 4; ++m) {
+        const int ch = chan_of(m, g, 0);
+        kbd[m] = *reinterpret_cast<const f32x4*>(cst + ch);
+        kbd[4 + m] = *reinterpret_cast<const f32x4*>(cst + H + ch);
+        kbxz[m] = *reinterpret_cast<const float4*>(cst + 128 + ch);
+        kbxc[m] = *reinterpret_cast<const float4*>(cst + 128 + H + ch);
+    }
+    const int W = gridDim.x * 4;                                     // every wave walks its own chunk sequence
+    int c = blockIdx.x * 4 + w;
+    if (c >= n_chunks) return;
+    constexpr bool fast = FAST;
+    BFrag ring[NSLOT];
+    CondOps cnd[2];
+    if (fast) fetch_c(c, cnd[0]);
 #pragma unroll
-            for (int u = 0; u < NSUB; ++u) fetch(cn0 + u < n_chunks ? cn0 + u : n_chunks - 1, nxts[u]);
-        }
+    for (int u = 0; u < NSLOT - 1; ++u) fetch_b(c + u * W, ring[u]);
+    // one round = NSLOT chunks with static ring slots.  The first round is peeled (called once ahead of the
+    // loop) so that the loop header sees the steady-state queue of outstanding loads and the compiler's
+    // vmcnt waits stay exact instead of draining the prefetch ring every round.
+    auto round = [&]() __attribute__((always_inline)) -> bool {
 #pragma unroll
-      for (int u = 0; u < NSUB; ++u) {
-        const int c = c0 + u;
-        if (c >= n_chunks) break;
-        const LayerOps& cur = curs[u];
-        const int b = c / chunks_per_b, t = (c - b * chunks_per_b) * 16 + n;
-        f32x4 acc[8];
-#pragma unroll
-        for (int mt = 0; mt < 8; ++mt) {
-            acc[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A[mt][ks], cur.b[ks], acc[mt], 0, 0, 0);
-        }
-        if (t < a.Tp) {
+        for (int u = 0; u < NSLOT; ++u) {
+            if (c >= n_chunks) return false;
+            if (fast) fetch_c(c + W, cnd[(u + 1) & 1]);
+            fetch_b(c + (NSLOT - 1) * W, ring[(u + NSLOT - 1) % NSLOT]);
+            const BFrag& cur = ring[u];
+            const CondOps& k = cnd[u & 1];
+            const int b = c / chunks_per_b, t = (c - b * chunks_per_b) * 16 + n;
+            f32x4 acc[8];                                   // = bd + Wd . [h(t-dil) ; h(t)]
+            mfma_first(acc, A, cur.b[0], kbd);
+            mfma_next<1, false, true>(acc, A, cur.b[1]);
+            mfma_next<2, false, false>(acc, A, cur.b[2]);
+            mfma_next<3, true, false>(acc, A, cur.b[3]);
+            const float wuz = k.wu * K_SIG, wuc = k.wu * K_TANH;
             unsigned short hv[16];
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const int c0 = chan_of(m, g, 0);
-                const float4 bdz = *reinterpret_cast<const float4*>(cst + c0);
-                const float4 bdc = *reinterpret_cast<const float4*>(cst + H + c0);
-                const float4 bxz = *reinterpret_cast<const float4*>(cst + 128 + c0);
-                const float4 bxc = *reinterpret_cast<const float4*>(cst + 128 + H + c0);
-                const float bdzv[4] = {bdz.x, bdz.y, bdz.z, bdz.w}, bdcv[4] = {bdc.x, bdc.y, bdc.z, bdc.w};
+                const int ch = chan_of(m, g, 0);
+                const float4 bxz = kbxz[m], bxc = kbxc[m];
                 float gz[4] = {bxz.x, bxz.y, bxz.z, bxz.w}, gc[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
-                if (a.seg == 1) {
-                    const float czv[4] = {cur.cz[m].x, cur.cz[m].y, cur.cz[m].z, cur.cz[m].w};
-                    const float ccv[4] = {cur.cc[m].x, cur.cc[m].y, cur.cc[m].z, cur.cc[m].w};
+                if (fast) {
+                    const float czv[4] = {k.cz[m].x, k.cz[m].y, k.cz[m].z, k.cz[m].w};
+                    const float ccv[4] = {k.cc[m].x, k.cc[m].y, k.cc[m].z, k.cc[m].w};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { gz[r] = fmaf(cur.wu, czv[r], gz[r]); gc[r] = fmaf(cur.wu, ccv[r], gc[r]); }
+                    for (int r = 0; r < 4; ++r) { gz[r] = fmaf(wuz, czv[r], gz[r]); gc[r] = fmaf(wuc, ccv[r], gc[r]); }
                 } else {
+                    float sz[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f};
                     for (int s = 0; s < a.seg; ++s) {
                         const int tt = t + s + a.coff;
                         int f = tt / a.U; const int jj = tt - f * a.U;
                         f = f < a.Tf ? f : a.Tf - 1;
                         const float wu = a.P[a.y.wup + jj];
-                        const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)(l * a.seg + s) * 128 + c0;
+                        const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)(l * a.seg + s) * 128 + ch;
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) { gz[r] = fmaf(wu, cr[r], gz[r]); gc[r] = fmaf(wu, cr[H + r], gc[r]); }
+                        for (int r = 0; r < 4; ++r) { sz[r] = fmaf(wu, cr[r], sz[r]); sc[r] = fmaf(wu, cr[H + r], sc[r]); }
                     }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { gz[r] = fmaf(K_SIG, sz[r], gz[r]); gc[r] = fmaf(K_TANH, sc[r], gc[r]); }
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float hp = (float)cur.b[2 + (m >> 1)][(m & 1) * 4 + r];      // h(t)[chan]: own tap-1 fragment
-                    const float z = sigm(gz[r] * (acc[m][r] + bdzv[r]));
-                    const float cd = tanh_c(gc[r] * (acc[4 + m][r] + bdcv[r]));
+                    const float z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(gz[r] * acc[m][r]));
+                    const float q = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(gc[r] * acc[4 + m][r]));
+                    const float cd = fmaf(-2.f, q, 1.f);
                     hv[m * 4 + r] = f2bf(fmaf(z, hp - cd, cd));                        // (1-z) c + z h
                 }
             }
+            if (t < a.Tp) {
+                uint4 o0, o1;
+                o0.x = hv[0] | ((unsigned)hv[1] << 16);   o0.y = hv[2] | ((unsigned)hv[3] << 16);
+                o0.z = hv[4] | ((unsigned)hv[5] << 16);   o0.w = hv[6] | ((unsigned)hv[7] << 16);
+                o1.x = hv[8] | ((unsigned)hv[9] << 16);   o1.y = hv[10] | ((unsigned)hv[11] << 16);
+                o1.z = hv[12] | ((unsigned)hv[13] << 16); o1.w = hv[14] | ((unsigned)hv[15] << 16);
+                unsigned short* dst = hnext + ((size_t)b * a.Tp + t) * H;
+                *reinterpret_cast<uint4*>(dst + 8 * g) = o0;
+                *reinterpret_cast<uint4*>(dst + 32 + 8 * g) = o1;
+            }
+            c += W;
+        }
+        return true;
+    };
+    if (!round()) return;
+    while (round()) {}
+}
+
+// ---- frame-unit variant of the gated layer (seg == 1, 16 <= U <= 112): the kernel the bf16 stack runs ------
+// Work is cut at conditioning-frame boundaries: a unit = the <= U positions of one utterance that share one
+// conditioning frame, walked as NCH = ceil(U/16) chunks of 16 positions (the last one ragged).  Every wave owns
+// a contiguous range of units.  Why: with one wave per SIMD every instruction of any kind costs an issue
+// slot, and all vector-memory returns are counted in order (vmcnt), so
+//   * the hoisted in_x row is loaded ONCE per unit (8 loads per ~7 chunks instead of 9 per chunk) and never
+//     sits between the streamed h rows in the in-order return queue: the B-fragment ring can run
+//     NCH-2 chunks ahead of its consumer without a conditioning wait draining it;
+//   * chunk/position arithmetic is a handful of scalar adds per chunk (no divisions);
+//   * ragged tails and the causal zero padding are out-of-range buffer offsets (loads return 0, stores are
+//     dropped): no exec-mask branches in the loop;
+//   * the 32 MFMAs of chunk i+1 are issued in four groups between the four epilogue quarters of chunk i
+//     (two accumulator sets), so the matrix pipe runs under the vector-ALU-bound epilogue.
+struct CondRow { float4 cz[4], cc[4]; };
+struct Unit { int b, f, ts, te, jj0; };        // wave-uniform: utterance, frame, [ts, te) positions, first tap index
+
+template <int NCH>
+__global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a, const int l, const int dil,
+                                                                  const int n_units, const int Fu) {
+    __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | prescaled bx[128] of this layer
+    __shared__ float wus[128];                                       // upsampler taps (U <= 112)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid]
+                         : a.P[a.y.bx + (size_t)l * 128 + tid - 128] * (tid < 192 ? K_SIG : K_TANH);
+    if (tid < 128) wus[tid] = tid < a.U ? a.P[a.y.wup + tid] : 0.f;
+    bf16x8 A[8][4];
+    {
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
+#pragma unroll
+        for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) A[mt][ks] = src[(mt * 4 + ks) * 64 + lane];
+    }
+    __syncthreads();
+    f32x4 kbd[8];
+    float4 kbxz[4], kbxc[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const int ch = chan_of(m, g, 0);
+        kbd[m] = *reinterpret_cast<const f32x4*>(cst + ch);
+        kbd[4 + m] = *reinterpret_cast<const f32x4*>(cst + H + ch);
+        kbxz[m] = *reinterpret_cast<const float4*>(cst + 128 + ch);
+        kbxc[m] = *reinterpret_cast<const float4*>(cst + 128 + H + ch);
+    }
+    const size_t lstride = (size_t)a.B * a.Tp * H;
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(a.hs + (size_t)(l + 1) * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
+    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_c = (unsigned)(8 * g) * 4u;
+    const unsigned dil_bytes = (unsigned)dil * H * 2u;
+
+    const int Wn = gridDim.x * 4, per = (n_units + Wn - 1) / Wn;     // contiguous unit range of this wave
+    const int j0 = (blockIdx.x * 4 + w) * per;
+    const int j1 = j0 + per < n_units ? j0 + per : n_units;
+    if (j0 >= j1) return;
+
+    auto unit_of = [&](int j) -> Unit {                              // scalar
+        Unit u;
+        const bool ok = j < j1;
+        const int jc = ok ? j : j1 - 1;
+        u.b = jc / Fu; u.f = jc - u.b * Fu;
+        const int s = u.f * a.U - a.coff, e = s + a.U;
+        u.ts = s > 0 ? s : 0;
+        u.te = ok ? (e < a.Tp ? e : a.Tp) : 0;                        // a unit past the range is empty
+        u.jj0 = u.ts - s;
+        return u;
+    };
+    auto fetch_b = [&](const Unit& u, int i, BFrag& fr) {
+        const int t0 = u.ts + 16 * i, t = t0 + n;
+        const unsigned base = (unsigned)(u.b * a.Tp + t0) * (H * 2u) + lane_h;
+        const bool ok = t < u.te;
+        const unsigned o1 = ok ? base : OOB;
+        const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
+        fr.b[0] = buf_ld_bf8(rh, o0); fr.b[1] = buf_ld_bf8(rh, o0 + 64u);
+        fr.b[2] = buf_ld_bf8(rh, o1); fr.b[3] = buf_ld_bf8(rh, o1 + 64u);
+    };
+    auto fetch_rows = [&](const Unit& u, CondRow& r) {
+        const int fc = u.f < a.Tf - 1 ? u.f : a.Tf - 1;
+        const unsigned off = (unsigned)((u.b * a.Tf + fc) * a.N + l * 128) * 4u + lane_c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {              // q: channel group (q>>1)*32 + 8g + 4*(q&1)
+            r.cz[q] = buf_ld_f4(rc, off + (unsigned)(32 * (q >> 1) + 4 * (q & 1)) * 4u);
+            r.cc[q] = buf_ld_f4(rc, off + (unsigned)(H + 32 * (q >> 1) + 4 * (q & 1)) * 4u);
+        }
+    };
+
+    Unit cu = unit_of(j0), nu = unit_of(j0 + 1);
+    CondRow cur;
+    fetch_rows(cu, cur);
+    BFrag ring[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH - 1; ++i) fetch_b(cu, i, ring[i]);
+    f32x4 acc[2][8];
+    mfma_first(acc[0], A, ring[0].b[0], kbd);
+    mfma_next<1, false, true>(acc[0], A, ring[0].b[1]);
+    mfma_next<2, false, false>(acc[0], A, ring[0].b[2]);
+    mfma_next<3, true, false>(acc[0], A, ring[0].b[3]);
+
+    // the body of one unit; the first unit is peeled (called once ahead of the loop) so that the loop header
+    // sees the steady-state queue of outstanding loads and the compiler's vmcnt waits do not drain the ring
+    auto unit_body = [&](const int j) __attribute__((always_inline)) {
+        CondRow nxt;
+        fetch_rows(nu, nxt);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (i == 0) fetch_b(cu, NCH - 1, ring[NCH - 1]);         // slot freed by the previous unit's last chunk
+            else fetch_b(nu, i - 1, ring[i - 1]);                    // slot freed by this unit's chunk i-1
+            const int t0 = cu.ts + 16 * i, t = t0 + n;
+            const float wu = wus[cu.jj0 + 16 * i + n];
+            const float wuz = wu * K_SIG, wuc = wu * K_TANH;
+            f32x4 (&ac)[8] = acc[i & 1];
+            f32x4 (&an)[8] = acc[(i + 1) & 1];
+            const BFrag& cb = ring[i];
+            const BFrag& nb = ring[(i + 1) % NCH];                   // i == NCH-1: slot 0 already holds (next unit, 0)
+            unsigned short hv[16];
+            auto epi = [&](const int m) __attribute__((always_inline)) {
+                const float czv[4] = {cur.cz[m].x, cur.cz[m].y, cur.cz[m].z, cur.cz[m].w};
+                const float ccv[4] = {cur.cc[m].x, cur.cc[m].y, cur.cc[m].z, cur.cc[m].w};
+                const float bz[4] = {kbxz[m].x, kbxz[m].y, kbxz[m].z, kbxz[m].w};
+                const float bc[4] = {kbxc[m].x, kbxc[m].y, kbxc[m].z, kbxc[m].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gz = fmaf(wuz, czv[r], bz[r]), gc = fmaf(wuc, ccv[r], bc[r]);
+                    const float hp = (float)cb.b[2 + (m >> 1)][(m & 1) * 4 + r];       // h(t)[chan]: own tap-1 fragment
+                    const float z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(gz * ac[m][r]));
+                    const float q = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(gc * ac[4 + m][r]));
+                    const float cd = fmaf(-2.f, q, 1.f);
+                    hv[m * 4 + r] = f2bf(fmaf(z, hp - cd, cd));                        // (1-z) c + z h
+                }
+            };
+            mfma_first(an, A, nb.b[0], kbd);                epi(0);
+            mfma_next<1, false, true>(an, A, nb.b[1]);      epi(1);
+            mfma_next<2, false, false>(an, A, nb.b[2]);      epi(2);
+            mfma_next<3, true, false>(an, A, nb.b[3]);       epi(3);
             uint4 o0, o1;
             o0.x = hv[0] | ((unsigned)hv[1] << 16);   o0.y = hv[2] | ((unsigned)hv[3] << 16);
             o0.z = hv[4] | ((unsigned)hv[5] << 16);   o0.w = hv[6] | ((unsigned)hv[7] << 16);
             o1.x = hv[8] | ((unsigned)hv[9] << 16);   o1.y = hv[10] | ((unsigned)hv[11] << 16);
             o1.z = hv[12] | ((unsigned)hv[13] << 16); o1.w = hv[14] | ((unsigned)hv[15] << 16);
-            unsigned short* dst = hnext + ((size_t)b * a.Tp + t) * H;
-            *reinterpret_cast<uint4*>(dst + 8 * g) = o0;
-            *reinterpret_cast<uint4*>(dst + 32 + 8 * g) = o1;
+            const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h : OOB;
+            typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rn, so + 64u, 0, 0);
         }
-      }
+        if (NCH & 1) {                                               // odd chunk count: realign the accumulator parity
 #pragma unroll
-        for (int u = 0; u < NSUB; ++u) curs[u] = nxts[u];
-    }
+            for (int mt = 0; mt < 8; ++mt) acc[0][mt] = acc[1][mt];
+        }
+        cur = nxt; cu = nu; nu = unit_of(j + 2);
+    };
+    unit_body(j0);
+    for (int j = j0 + 1; j < j1; ++j) unit_body(j);
 }
 
 // ---- head: skip (K = L*64) -> relu -> out_1 (128x128) -> relu -> out_2 (<=16 x 128) ----------------
@@ -414,6 +656,8 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     if (!packed || !wbf || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
     if (Tp < 1) return SWN_E_BADARG;
+    // 32-bit buffer offsets in the layer kernel: one layer of hidden states and the conditioning must stay < 2 GiB
+    if ((size_t)batch * Tp * H * 2 >= (1ull << 31) || (size_t)batch * n_frames * g.N * 4 >= (1ull << 31)) return SWN_E_UNSUPPORTED;
     BfArgs a;
     swn_make_layout(&g, &a.y);
     const BfOffsets o = bf_offsets(g);
@@ -427,9 +671,21 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     hipLaunchKernelGGL(bf16_input_kernel, dim3((unsigned)((Tp + 63) / 64), batch), dim3(256), 0, st, a);
     const int n_tiles = batch * (int)((Tp + TN - 1) / TN);
     const int n_chunks = batch * (int)((Tp + 15) / 16);
-    const int grid = (n_chunks + 7) / 8 < 256 ? (n_chunks + 7) / 8 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
-    for (int l = 0; l < g.L; ++l)
-        hipLaunchKernelGGL(bf16_layer_kernel, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
+    const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
+    const int nch = (g.U + 15) / 16;
+    if (g.seg == 1 && g.U >= 16 && nch <= 7) {
+        const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frame units per utterance
+        const int n_units = batch * Fu;
+        const int ug = (n_units + 3) / 4 < 256 ? (n_units + 3) / 4 : 256;
+        for (int l = 0; l < g.L; ++l) {
+            if (nch <= 4) hipLaunchKernelGGL(bf16_layer_units_kernel<4>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu);
+            else if (nch == 5) hipLaunchKernelGGL(bf16_layer_units_kernel<5>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu);
+            else hipLaunchKernelGGL(bf16_layer_units_kernel<7>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu);
+        }
+    } else {
+        for (int l = 0; l < g.L; ++l)
+            hipLaunchKernelGGL(bf16_layer_kernel<false>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
+    }
     const int hgrid = n_tiles < 512 ? n_tiles : 512;
     hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 0, st, a, n_tiles);
     return swn_launch_status("swn_forward_bf16");
