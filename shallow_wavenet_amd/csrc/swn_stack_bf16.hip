@@ -17,11 +17,15 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include "swn_geom.hpp"
+#include <cstdlib>
 
 namespace {
 
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
 
 constexpr int H = 64;
 constexpr int TN = 64;                 // positions per tile
@@ -329,7 +333,7 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
 // ---- frame-unit variant of the gated layer (seg == 1, 16 <= U <= 112): the kernel the bf16 stack runs ------
 // Work is cut at conditioning-frame boundaries: a unit = the <= U positions of one utterance that share one
 // conditioning frame, walked as NCH = ceil(U/16) chunks of 16 positions (the last one ragged).  Every wave owns
-// a contiguous range of units.  Why: with one wave per SIMD every instruction of any kind costs an issue
+// units j, j + #waves, ...  Why: with one wave per SIMD every instruction of any kind costs an issue
 // slot, and all vector-memory returns are counted in order (vmcnt), so
 //   * the hoisted in_x row is loaded ONCE per unit (8 loads per ~7 chunks instead of 9 per chunk) and never
 //     sits between the streamed h rows in the in-order return queue: the B-fragment ring can run
@@ -379,9 +383,10 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
     const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_c = (unsigned)(8 * g) * 4u;
     const unsigned dil_bytes = (unsigned)dil * H * 2u;
 
-    const int Wn = gridDim.x * 4, per = (n_units + Wn - 1) / Wn;     // contiguous unit range of this wave
-    const int j0 = (blockIdx.x * 4 + w) * per;
-    const int j1 = j0 + per < n_units ? j0 + per : n_units;
+    const int Wn = gridDim.x * 4;
+    // a wave walks units j0, j0+Wn, ...: at any time the chip streams one contiguous window of the layer
+    // (measured 7 % faster than giving every wave its own contiguous range of units)
+    const int js = Wn, j0 = blockIdx.x * 4 + w, j1 = n_units;
     if (j0 >= j1) return;
 
     auto unit_of = [&](int j) -> Unit {                              // scalar
@@ -414,7 +419,7 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
         }
     };
 
-    Unit cu = unit_of(j0), nu = unit_of(j0 + 1);
+    Unit cu = unit_of(j0), nu = unit_of(j0 + js);
     CondRow cur;
     fetch_rows(cu, cur);
     BFrag ring[NCH];
@@ -442,33 +447,37 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
             f32x4 (&an)[8] = acc[(i + 1) & 1];
             const BFrag& cb = ring[i];
             const BFrag& nb = ring[(i + 1) % NCH];                   // i == NCH-1: slot 0 already holds (next unit, 0)
-            unsigned short hv[16];
+            unsigned hw[8];                                          // 16 finished channels, two bf16 per word
             auto epi = [&](const int m) __attribute__((always_inline)) {
-                const float czv[4] = {cur.cz[m].x, cur.cz[m].y, cur.cz[m].z, cur.cz[m].w};
-                const float ccv[4] = {cur.cc[m].x, cur.cc[m].y, cur.cc[m].z, cur.cc[m].w};
-                const float bz[4] = {kbxz[m].x, kbxz[m].y, kbxz[m].z, kbxz[m].w};
-                const float bc[4] = {kbxc[m].x, kbxc[m].y, kbxc[m].z, kbxc[m].w};
+                // two channels per instruction (v_pk_fma/mul/add_f32); exp2 / rcp stay per element
+                const v2f cz2[2] = {{cur.cz[m].x, cur.cz[m].y}, {cur.cz[m].z, cur.cz[m].w}};
+                const v2f cc2[2] = {{cur.cc[m].x, cur.cc[m].y}, {cur.cc[m].z, cur.cc[m].w}};
+                const v2f bz2[2] = {{kbxz[m].x, kbxz[m].y}, {kbxz[m].z, kbxz[m].w}};
+                const v2f bc2[2] = {{kbxc[m].x, kbxc[m].y}, {kbxc[m].z, kbxc[m].w}};
+                const v2f wuz2 = {wuz, wuz}, wuc2 = {wuc, wuc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float gz = fmaf(wuz, czv[r], bz[r]), gc = fmaf(wuc, ccv[r], bc[r]);
-                    const float hp = (float)cb.b[2 + (m >> 1)][(m & 1) * 4 + r];       // h(t)[chan]: own tap-1 fragment
-                    const float z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(gz * ac[m][r]));
-                    const float q = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(gc * ac[4 + m][r]));
-                    const float cd = fmaf(-2.f, q, 1.f);
-                    hv[m * 4 + r] = f2bf(fmaf(z, hp - cd, cd));                        // (1-z) c + z h
+                for (int p = 0; p < 2; ++p) {
+                    const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[4 + m][2 * p], ac[4 + m][2 * p + 1]};
+                    const v2f pz = (wuz2 * cz2[p] + bz2[p]) * az, pc = (wuc2 * cc2[p] + bc2[p]) * acd;
+                    const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
+                    const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
+                    const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
+                    const v2f q = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
+                    const v2f cd = mtwo * q + one;
+                    const unsigned hpw = __builtin_bit_cast(u32x4, cb.b[2 + (m >> 1)])[(m & 1) * 2 + p];   // own tap-1 fragment
+                    const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
+                    const v2f o = z * (hp - cd) + cd;                                  // (1-z) c + z h
+                    hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));    // one v_cvt_pk_bf16_f32
                 }
             };
             mfma_first(an, A, nb.b[0], kbd);                epi(0);
             mfma_next<1, false, true>(an, A, nb.b[1]);      epi(1);
-            mfma_next<2, false, false>(an, A, nb.b[2]);      epi(2);
-            mfma_next<3, true, false>(an, A, nb.b[3]);       epi(3);
+            mfma_next<2, false, false>(an, A, nb.b[2]);     epi(2);
+            mfma_next<3, true, false>(an, A, nb.b[3]);      epi(3);
             uint4 o0, o1;
-            o0.x = hv[0] | ((unsigned)hv[1] << 16);   o0.y = hv[2] | ((unsigned)hv[3] << 16);
-            o0.z = hv[4] | ((unsigned)hv[5] << 16);   o0.w = hv[6] | ((unsigned)hv[7] << 16);
-            o1.x = hv[8] | ((unsigned)hv[9] << 16);   o1.y = hv[10] | ((unsigned)hv[11] << 16);
-            o1.z = hv[12] | ((unsigned)hv[13] << 16); o1.w = hv[14] | ((unsigned)hv[15] << 16);
+            o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
+            o1.x = hw[4]; o1.y = hw[5]; o1.z = hw[6]; o1.w = hw[7];
             const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h : OOB;
-            typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rn, so + 64u, 0, 0);
         }
@@ -476,15 +485,15 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
 #pragma unroll
             for (int mt = 0; mt < 8; ++mt) acc[0][mt] = acc[1][mt];
         }
-        cur = nxt; cu = nu; nu = unit_of(j + 2);
+        cur = nxt; cu = nu; nu = unit_of(j + 2 * js);
     };
     unit_body(j0);
-    for (int j = j0 + 1; j < j1; ++j) unit_body(j);
+    for (int j = j0 + js; j < j1; j += js) unit_body(j);
 }
 
 // ---- head: skip (K = L*64) -> relu -> out_1 (128x128) -> relu -> out_2 (<=16 x 128) ----------------
 template <int LL>
-__global__ __launch_bounds__(256) void bf16_head_kernel(const BfArgs a, const int n_tiles) {
+__global__ __launch_bounds__(256, 1) void bf16_head_kernel(const BfArgs a, const int n_tiles) {
     constexpr int ROW2 = 256 + 16;               // [pos][128 ch] bf16 tile pitch
     __shared__ __attribute__((aligned(16))) unsigned char t1[TN * ROW2];
     __shared__ __attribute__((aligned(16))) unsigned char t2[TN * ROW2];
@@ -519,27 +528,39 @@ __global__ __launch_bounds__(256) void bf16_head_kernel(const BfArgs a, const in
     for (int r = 0; r < 4; ++r) b2[r] = (4 * g + r < a.NO) ? a.P[a.y.b2 + 4 * g + r] : 0.f;
     const size_t lstride = (size_t)a.B * a.Tp * H;
     const int tiles_per_b = (a.Tp + TN - 1) / TN;
+    __amdgpu_buffer_rsrc_t rl[LL];                                   // hidden states of layers 1..L
+#pragma unroll
+    for (int q = 0; q < LL; ++q) rl[q] = make_rsrc(a.hs + (size_t)(1 + q) * lstride, lstride * 2);
+
+    // One workgroup per CU with the whole register file: the 48 B fragments of a 64-position tile (6 layers x
+    // 64 positions x 128 B) are fetched one tile ahead, each 16-position column refilled as soon as its MFMAs
+    // have consumed it, so the HBM stream keeps running under the LDS / barrier phases of out_1 and out_2.
+    // Loads are branch-free buffer loads: a position past the end is an out-of-range offset and reads zeros.
+    bf16x8 ring[4][KS1];
+    auto fetch_col = [&](int tix, int nt, bf16x8 (&col)[KS1]) {
+        const int tc = tix < n_tiles ? tix : n_tiles - 1;
+        const int b = tc / tiles_per_b, t = (tc - b * tiles_per_b) * TN + 16 * nt + n;
+        const unsigned off = (tix < n_tiles && t < a.Tp) ? (unsigned)(b * a.Tp + t) * (H * 2u) + (unsigned)(8 * g) * 2u : OOB;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks) col[ks] = buf_ld_bf8(rl[ks / 2], off + 64u * (ks & 1));
+    };
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) fetch_col(blockIdx.x, nt, ring[nt]);
 
     for (int tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         const int b = tix / tiles_per_b, t0 = (tix - b * tiles_per_b) * TN;
         // ---- skip = Wsk . [h_1 .. h_L]
         f32x4 acc[2][4];
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
-#pragma unroll
-            for (int nt = 0; nt < 4; ++nt) acc[m][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const int t = t0 + 16 * nt + n;
+            acc[0][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            acc[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                bf16x8 bf = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
-                if (t < a.Tp)
-                    bf = *reinterpret_cast<const bf16x8*>(a.hs + (size_t)(1 + ks / 2) * lstride +
-                                                          ((size_t)b * a.Tp + t) * H + 32 * (ks & 1) + 8 * g);
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[0][ks], bf, acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[1][ks], bf, acc[1][nt], 0, 0, 0);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[0][ks], ring[nt][ks], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[1][ks], ring[nt][ks], acc[1][nt], 0, 0, 0);
             }
+            fetch_col(tix + gridDim.x, nt, ring[nt]);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -686,7 +707,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
         for (int l = 0; l < g.L; ++l)
             hipLaunchKernelGGL(bf16_layer_kernel<false>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
     }
-    const int hgrid = n_tiles < 512 ? n_tiles : 512;
+    const int hgrid = n_tiles < 256 ? n_tiles : 256;
     hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 0, st, a, n_tiles);
     return swn_launch_status("swn_forward_bf16");
 }
