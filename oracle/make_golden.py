@@ -282,6 +282,13 @@ def main():
     jobs.append(("g0_tiny_lap_nowav_s1l0", gen_laplace,
                  dict(cfg=C.tiny("laplace", 1, 0, wav_conv_flag=False), frames=[8, 6], wseed=12,
                       flavor="trained", aux_seed=3, noise_seed=6, with_grads=True)))
+    # the (seg,1) Conv2d ahead of in_x (aux_conv2d_flag, cswnv_shift1.py:196-198)
+    jobs.append(("g0_tiny_lap_c2d_s5l4_xavier", gen_laplace,
+                 dict(cfg=C.tiny("laplace", 5, 4, aux_conv2d_flag=True), frames=[8, 6], wseed=15,
+                      flavor="xavier", aux_seed=3, noise_seed=5, with_grads=True)))
+    jobs.append(("g0_tiny_lap_c2d_s2l0_trained", gen_laplace,
+                 dict(cfg=C.tiny("laplace", 2, 0, aux_conv2d_flag=True), frames=[8, 6], wseed=16,
+                      flavor="trained", aux_seed=3, noise_seed=6)))
     jobs.append(("g0_tiny_softmax", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[8, 6], wseed=13,
                       flavor="xavier", aux_seed=3, noise_seed=7, with_grads=True)))

@@ -195,7 +195,7 @@ def ref6_softmax() -> NetConfig:
 
 
 def tiny(kind: str = "laplace", seg: int = 1, lpc: int = 0, wav_conv_flag: bool = True,
-         audio_in_flag: bool = False) -> NetConfig:
+         audio_in_flag: bool = False, aux_conv2d_flag: bool = False) -> NetConfig:
     """G0 fixture shape: n_aux=10 U=20 H=32 S=48 K=3 dd=3 dr=2 (rf=54)."""
     if kind == "softmax":
         return NetConfig(kind="softmax", n_aux=10, hid_chn=32, skip_chn=48, dilation_depth=3,
@@ -203,4 +203,4 @@ def tiny(kind: str = "laplace", seg: int = 1, lpc: int = 0, wav_conv_flag: bool 
                          wav_conv_flag=wav_conv_flag, audio_in_flag=audio_in_flag)
     return NetConfig(kind="laplace", n_aux=10, hid_chn=32, skip_chn=48, dilation_depth=3,
                      dilation_repeat=2, kernel_size=3, upsampling_factor=20, seg=seg, lpc=lpc,
-                     wav_conv_flag=wav_conv_flag)
+                     wav_conv_flag=wav_conv_flag, aux_conv2d_flag=aux_conv2d_flag)

@@ -80,6 +80,10 @@ extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int
     const float* bup = t[ti++];
     memcpy(out + y.wup, wup, sizeof(float) * g.U);
     out[y.bup] = bup[0];
+    // ---- optional (seg,1) Conv2d between the upsampler and in_x (cswnv_shift1.py:196-198): linear, so it is
+    //      folded into in_x below:  W_eff[o][c*seg+s] = sum_p in_x.W[o][p] * conv2d.W[p][c][s]
+    const float* c2w = nullptr; const float* c2b = nullptr;
+    if (g.conv2d) { c2w = t[ti++]; c2b = t[ti++]; }
     // ---- sample lift (optional) and causal input layer
     const float* wav_w = nullptr; const float* wav_b = nullptr;
     if (g.wav) { wav_w = t[ti++]; wav_b = t[ti++]; }
@@ -120,18 +124,28 @@ extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int
     }
     // ---- in_x: stacked rows for the frame-rate GEMM, bias folded with the upsampler bias
     const int A = g.A0 * seg + (g.audio_in ? Q : 0);
+    std::vector<double> eff(g.conv2d ? (size_t)g.A0 * seg : 0);
     for (int l = 0; l < L; ++l) {
-        const float* w = t[ti++];       // (2H, A, 1)
+        const float* w = t[ti++];       // (2H, A, 1); with the Conv2d: (2H, A0, 1)
         const float* b = t[ti++];
         for (int o = 0; o < H2; ++o) {
-            double ws = 0;
+            double ws = 0, bo = b[o];
+            if (g.conv2d) {
+                std::fill(eff.begin(), eff.end(), 0.0);
+                for (int p = 0; p < g.A0; ++p) {
+                    const double wp = w[(size_t)o * g.A0 + p];
+                    const float* row = c2w + (size_t)p * g.A0 * seg;      // [c][s] of output channel p
+                    for (int cs = 0; cs < g.A0 * seg; ++cs) eff[cs] += wp * row[cs];
+                    bo += wp * c2b[p];
+                }
+            }
             for (int c = 0; c < g.A0; ++c)
                 for (int s = 0; s < seg; ++s) {
-                    float v = w[(size_t)o * A + c * seg + s];
+                    const float v = g.conv2d ? (float)eff[(size_t)c * seg + s] : w[(size_t)o * A + c * seg + s];
                     ws += v;
                     out[y.wx + ((size_t)(l * seg + s) * H2 + o) * g.A0p + c] = v;
                 }
-            out[y.bx + (size_t)l * H2 + o] = (float)((double)b[o] + (double)bup[0] * ws);
+            out[y.bx + (size_t)l * H2 + o] = (float)(bo + (double)bup[0] * ws);
             if (g.audio_in)
                 for (int q = 0; q < Q; ++q)
                     out[y.wxa + ((size_t)l * Q + q) * H2 + o] = w[(size_t)o * A + g.A0 + q];

@@ -34,12 +34,26 @@ def unfold_packed_grads(cfg: NetConfig, gp: torch.Tensor, params: Dict[str, torc
     gwx = sec("wx", L * seg * H2 * A0p).view(L, seg, H2, A0p)[..., :A0]            # [l][s][o][c]
     b_up = params["upsampling.conv.bias"].reshape(())
     g["upsampling.conv.weight"] = sec("wup", U).view(1, 1, 1, U)
-    wsum = torch.stack([params[f"in_x.{l}.weight"][:, : A0 * seg, 0].sum(1) for l in range(L)])   # [l][o]
+    c2d = cfg.kind == "laplace" and cfg.aux_conv2d_flag and seg > 1
+    if c2d:   # in_x was packed as W_eff = W_in @ W2f, b_eff = b_in + W_in @ b2  (csrc/swn_pack.cpp)
+        w2f = params["aux_conv2d.weight"][..., 0].reshape(A0, A0 * seg)                          # [p][c*seg+s]
+        b2 = params["aux_conv2d.bias"]
+        weff = [params[f"in_x.{l}.weight"][:, :, 0] @ w2f for l in range(L)]
+        g["aux_conv2d.weight"] = torch.zeros_like(params["aux_conv2d.weight"])
+        g["aux_conv2d.bias"] = torch.zeros_like(b2)
+    else:
+        weff = [params[f"in_x.{l}.weight"][:, : A0 * seg, 0] for l in range(L)]
+    wsum = torch.stack([w.sum(1) for w in weff])                                                  # [l][o]
     g["upsampling.conv.bias"] = (gbx * wsum).sum().reshape(1)
     for l in range(L):
         gw = gwx[l].permute(1, 2, 0).reshape(H2, A0 * seg) + gbx[l][:, None] * b_up        # [o][c*seg+s]
         if cfg.kind == "softmax" and cfg.audio_in_flag:
             raise NotImplementedError("audio_in_flag gradients are not built")
+        if c2d:
+            w_in = params[f"in_x.{l}.weight"][:, :, 0]
+            g["aux_conv2d.weight"] += (w_in.t() @ gw).reshape(A0, A0, seg, 1)
+            g["aux_conv2d.bias"] += w_in.t() @ gbx[l]
+            gw = gw @ w2f.t() + gbx[l][:, None] * b2[None, :]
         g[f"in_x.{l}.weight"] = gw.unsqueeze(2)
         g[f"in_x.{l}.bias"] = gbx[l]
     gcb = sec("cb", H)

@@ -48,8 +48,14 @@ def test_bad_descriptors_are_rejected():
     d.kernel_size = 1
     assert lib.swn_receptive_field(ctypes.byref(d)) == -1
     d = _lib.desc_from_cfg(C.bl6_laplace(5, 4))
-    d.aux_conv2d_flag = 1
+    d.seg = 11
     assert lib.swn_packed_floats(ctypes.byref(d)) == 0
+    # the (seg,1) Conv2d is folded into in_x: two more tensors, same packed size
+    d = _lib.desc_from_cfg(C.bl6_laplace(5, 4))
+    n0, p0 = lib.swn_num_tensors(ctypes.byref(d)), lib.swn_packed_floats(ctypes.byref(d))
+    d.aux_conv2d_flag = 1
+    assert lib.swn_num_tensors(ctypes.byref(d)) == n0 + 2
+    assert lib.swn_packed_floats(ctypes.byref(d)) == p0
     with pytest.raises(KeyError):
         pack_state_dict(C.tiny(), {})
 
