@@ -79,8 +79,8 @@ int         swn_num_tensors(const swn_net_desc* d);
  * checkpoint per process instead). */
 size_t swn_packed_floats(const swn_net_desc* d);
 /* float offsets of the packed sections in the order scale_w, scale_b, aux_w[0..3], aux_b[0..3], wx, wxa, wup,
- * bup, bx, cb, cv, cc, ct, wd, bd, wsk, bsk, w1, b1, w2, b2, total (csrc/swn_geom.hpp::SwnLayout); returns
- * the number written (28) or a negative SWN_E_*.  Used to unfold swn_backward's packed gradients. */
+ * bup, bx, cb, cv, cc, ct, wd, bd, wsk, bsk, w1, b1, w2, b2, total, bxr (csrc/swn_geom.hpp::SwnLayout); returns
+ * the number written (29) or a negative SWN_E_*.  Used to unfold swn_backward's packed gradients. */
 int    swn_layout_offsets(const swn_net_desc* d, size_t* out, int n);
 int    swn_pack_params(const swn_net_desc* d, const float* const* tensors_host, int n_tensors,
                        float* packed_host, size_t packed_floats);
@@ -172,6 +172,26 @@ int    swn_backward(const swn_net_desc* d, const float* packed_dev, const float*
                     const float* fe_work_dev, const void* audio_dev, const float* fwd_work_dev,
                     const float* hs_dev, const float* grad_out_dev, int batch, int n_frames,
                     float* work_dev, float* gpacked_dev, void* stream);
+/* ---- training-mode forward / backward WITH DROPOUT  (model.train(), forward(..., do=True) with do_prob > 0:
+ *      cswnv_shift1.py:194-195,211-217,269-273 ; dswnv.py:253-254,264-270,278-282) --------------------------
+ * The reference draws its Bernoulli masks inside nn.Dropout; here they are explicit inputs, like the decode
+ * noise, so that the host can draw them with the torch CPU generator in the reference's order:
+ *   drop_x_dev   (B, A0, T - coff) multiplicative mask (0 or 1/(1-p)) on the upsampled conditioning
+ *                (A0 = n_aux * aux_kernel^aux_layers, coff = seg | 1 for softmax)
+ *   drop_h_host  HOST array of L device pointers: drop_h[l] = (B, H, Tp) mask on the hidden state that layer l
+ *                hands to layer l+1 (its skip output is not masked), NULL where the reference does not drop
+ * aux_drop acts at sample rate, so the frame-rate hoisting of in_x does not apply: in_x is evaluated as a
+ * sample-rate GEMM on the masked conditioning (no cond_dev input; fe_work_dev = swn_frontend's work buffer).
+ * fwd_work_dev of swn_backward_drop must be the buffer swn_forward_drop filled. */
+size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames);
+int    swn_forward_drop(const swn_net_desc* d, const float* packed_dev, const float* fe_work_dev, const void* audio_dev,
+                        int batch, int n_frames, const float* drop_x_dev, const float* const* drop_h_host,
+                        float* work_dev, float* out_dev, float* hs_dev, void* stream);
+size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames);
+int    swn_backward_drop(const swn_net_desc* d, const float* packed_dev, const float* aux_dev, const float* fe_work_dev,
+                         const void* audio_dev, const float* fwd_work_dev, const float* hs_dev,
+                         const float* drop_x_dev, const float* const* drop_h_host, const float* grad_out_dev,
+                         int batch, int n_frames, float* work_dev, float* gpacked_dev, void* stream);
 /* gradient of swn_laplace_head: grads wrt mu / b / logb / a (time-major, any may be NULL) -> grad wrt raw */
 int    swn_laplace_head_backward(const swn_net_desc* d, const float* out_dev, int batch, int tp,
                                  const float* gmu_dev, const float* gb_dev, const float* glogb_dev,

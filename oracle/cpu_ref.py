@@ -150,11 +150,17 @@ def _lift(cfg, P, audio: torch.Tensor) -> torch.Tensor:
 
 
 # --------------------------------------------------------------------------- Laplace model
-def laplace_stack(cfg, P, aux: torch.Tensor, audio: torch.Tensor):
+def laplace_stack(cfg, P, aux: torch.Tensor, audio: torch.Tensor, drop=None):
     """raw out_2 output (B, n_out, T-2seg+1) of the teacher-forced stack plus the per-layer
-    hidden states (used by kernel-level tests)."""
+    hidden states (used by kernel-level tests).  drop = (drop_x, [mask or None per layer]) restates the
+    training-mode dropout of cswnv_shift1.py:194-195,211-217,269-273 with explicit multiplicative masks:
+    `aux_drop` on the upsampled conditioning, `dcrnn_drop` on the hidden state a dropped layer passes on
+    (its skip output uses the undropped state)."""
     seg = cfg.seg
-    x = _stack_seg(cfg, P, upsample(cfg, P, frontend(cfg, P, aux))[:, :, seg:])
+    x = upsample(cfg, P, frontend(cfg, P, aux))[:, :, seg:]
+    if drop is not None:
+        x = x * drop[0]
+    x = _stack_seg(cfg, P, x)
     h = F.softsign(causal_conv(_lift(cfg, P, audio), P["causal.conv.weight"],
                                P["causal.conv.bias"], 1)[:, :, seg - 1:])
     hs = [h]
@@ -162,6 +168,8 @@ def laplace_stack(cfg, P, aux: torch.Tensor, audio: torch.Tensor):
     for l in range(cfg.L):
         sk, h = gated_layer(cfg, P, l, x, h)
         hs.append(h)
+        if drop is not None and drop[1][l] is not None:
+            h = h * drop[1][l]
         tot = sk if tot is None else tot + sk
     return head(cfg, P, tot), hs
 
@@ -277,10 +285,13 @@ def laplace_generate(cfg, P, aux: torch.Tensor, n_samples_list: Sequence[int], n
 
 
 # --------------------------------------------------------------------------- softmax model
-def softmax_stack(cfg, P, audio_idx: torch.Tensor, aux: torch.Tensor):
-    """teacher-forced logits (B, Q, T) and hidden states; audio_idx int64 (B, T)."""
+def softmax_stack(cfg, P, audio_idx: torch.Tensor, aux: torch.Tensor, drop=None):
+    """teacher-forced logits (B, Q, T) and hidden states; audio_idx int64 (B, T); drop as in laplace_stack
+    (dswnv.py:253-254,264-270)."""
     oh = one_hot(audio_idx, cfg.n_quantize).transpose(1, 2)          # B,Q,T
     x = upsample(cfg, P, frontend(cfg, P, aux))[:, :, 1:]
+    if drop is not None:
+        x = x * drop[0]
     if cfg.audio_in_flag:
         x = torch.cat((x, oh), 1)
     h = F.softsign(causal_conv(_lift(cfg, P, oh), P["causal.conv.weight"], P["causal.conv.bias"], 1))
@@ -289,6 +300,8 @@ def softmax_stack(cfg, P, audio_idx: torch.Tensor, aux: torch.Tensor):
     for l in range(cfg.L):
         sk, h = gated_layer(cfg, P, l, x, h)
         hs.append(h)
+        if drop is not None and drop[1][l] is not None:
+            h = h * drop[1][l]
         tot = sk if tot is None else tot + sk
     return head(cfg, P, tot), hs
 

@@ -213,6 +213,70 @@ def gen_softmax(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, head_str
           f"min margin={margin.min():.2e}")
 
 
+def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p):
+    """training-mode forward + backward WITH dropout (model.train(), do=True, do_prob=p): the masks the reference
+    draws are re-derived with shallow_wavenet_amd.noise.dropout_masks from the same seed and checked through the
+    oracle against the reference's own outputs before anything is stored."""
+    from shallow_wavenet_amd import noise as swn_noise
+    t0 = time.time()
+    mod = ref_d.DSWNV if cfg.kind == "softmax" else ref_c.CSWNV
+    m = mod(**cfg.ctor_kwargs(), do_prob=p)
+    sd = synth_state_dict(cfg, seed=wseed, flavor=flavor)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.train()
+    aux = ragged_aux(cfg, frames, aux_seed)
+    B, T = len(frames), max(frames) * cfg.U
+    rng = np.random.Generator(np.random.PCG64([aux_seed, 9]))
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, flavor=np.array(flavor), frames=np.array(frames),
+               aux=aux, drop_seed=drop_seed, drop_p=np.float64(p))
+    P = cpu_ref.as_params(sd)
+    if cfg.kind == "laplace":
+        audio = rng.uniform(-0.9, 0.9, size=(B, 1, T - cfg.seg)).astype(np.float32)
+        torch.manual_seed(drop_seed)
+        res = m(torch.from_numpy(aux), torch.from_numpy(audio), do=True, clip=False)
+        torch.manual_seed(drop_seed)
+        drop = swn_noise.dropout_masks(cfg, B, max(frames), p)
+        raw, _ = cpu_ref.laplace_stack(cfg, P, torch.from_numpy(aux), torch.from_numpy(audio), drop=drop)
+        mu_o = raw.transpose(1, 2)[:, :, :cfg.seg].reshape(res[0].shape)
+        err = (mu_o - res[0].detach()).abs().max().item()
+        assert err < 2e-5, f"regenerated dropout masks do not reproduce the reference ({err})"
+        out["fwd_audio"] = audio
+        for i, r in enumerate(res):
+            out[f"fwd_{i}"] = r.detach().numpy()
+        mu, b, log_b = res[0], res[1], res[2]
+        tgt = torch.from_numpy(rng.uniform(-0.9, 0.9, size=tuple(mu.shape)).astype(np.float32))
+        loss = ref_c.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
+        if cfg.lpc > 0:
+            loss = loss + 0.1 * res[3].pow(2).mean()
+    else:
+        Q = cfg.n_quantize
+        idx_in = rng.integers(0, Q, size=(B, T - 1)).astype(np.int64)
+        oh = ref_d.OneHot(torch.from_numpy(idx_in), Q).transpose(1, 2)
+        torch.manual_seed(drop_seed)
+        logits = m(oh, torch.from_numpy(aux), do=True)
+        torch.manual_seed(drop_seed)
+        drop = swn_noise.dropout_masks(cfg, B, max(frames), p)
+        raw, _ = cpu_ref.softmax_stack(cfg, P, torch.from_numpy(idx_in), torch.from_numpy(aux), drop=drop)
+        err = (raw.transpose(1, 2) - logits.detach()).abs().max().item()
+        assert err < 2e-4, f"regenerated dropout masks do not reproduce the reference ({err})"
+        out["fwd_audio_idx"] = idx_in
+        out["fwd_logits_dig"] = digest(logits.detach().numpy())
+        out["fwd_logits_head"] = logits.detach().numpy()[:, :64]
+        out["fwd_logits_tail"] = logits.detach().numpy()[:, -64:]
+        tgt = torch.from_numpy(rng.integers(0, Q, size=(B, T - 1)).astype(np.int64))
+        loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, Q), tgt.reshape(-1))
+    loss.backward()
+    out["loss_target"] = tgt.numpy()
+    out["loss"] = np.float64(loss.item())
+    for k, prm in m.named_parameters():
+        gnp = prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+        out[f"gdig_{k}"] = digest(gnp)
+        if gnp.size <= 4096:
+            out[f"grad_{k}"] = gnp
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: B={B} p={p} mask check err={err:.2e} loss={loss.item():.4f} {time.time() - t0:.1f}s")
+
+
 def gen_numerics():
     """G3: mu-law tables, Laplace transform grid, geometry and state-dict listings."""
     out = {}
@@ -289,6 +353,17 @@ def main():
     jobs.append(("g0_tiny_lap_c2d_s2l0_trained", gen_laplace,
                  dict(cfg=C.tiny("laplace", 2, 0, aux_conv2d_flag=True), frames=[8, 6], wseed=16,
                       flavor="trained", aux_seed=3, noise_seed=6)))
+    # training-mode dropout (run.sh trains with do_prob=0.5): forward + gradients
+    jobs.append(("g5_drop_tiny_lap_s1l0", gen_dropout,
+                 dict(cfg=C.tiny("laplace", 1, 0), frames=[6, 5], wseed=31, flavor="xavier", aux_seed=3, drop_seed=41, p=0.5)))
+    jobs.append(("g5_drop_tiny_lap_s5l4", gen_dropout,
+                 dict(cfg=C.tiny("laplace", 5, 4), frames=[6, 5], wseed=32, flavor="xavier", aux_seed=3, drop_seed=42, p=0.5)))
+    jobs.append(("g5_drop_tiny_lap_c2d_s2l4", gen_dropout,
+                 dict(cfg=C.tiny("laplace", 2, 4, aux_conv2d_flag=True), frames=[6, 6], wseed=33, flavor="xavier",
+                      aux_seed=3, drop_seed=43, p=0.3)))
+    jobs.append(("g5_drop_tiny_softmax", gen_dropout,
+                 dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[6, 5], wseed=34, flavor="xavier", aux_seed=3,
+                      drop_seed=44, p=0.5)))
     jobs.append(("g0_tiny_softmax", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[8, 6], wseed=13,
                       flavor="xavier", aux_seed=3, noise_seed=7, with_grads=True)))

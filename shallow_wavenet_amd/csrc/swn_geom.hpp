@@ -45,6 +45,7 @@ struct SwnLayout {
     // ---- sample-rate section
     size_t wup, bup;                         // [U], [1]
     size_t bx;                               // [L][2H] = in_x bias + b_up * sum_c,s W
+    size_t bxr;                              // [L][2H] = in_x bias alone (dropout mode: in_x runs at sample rate)
     size_t cb;                               // causal bias [H]
     size_t cv, cc;                           // laplace: fused lift+causal taps [K][H] (value, constant)
     size_t ct;                               // softmax: gather table [K][Q][H]
@@ -122,6 +123,7 @@ static inline __host__ void swn_make_layout(const SwnGeom* g, SwnLayout* y) {
     y->wup = o; o = swn_al(o + g->U);
     y->bup = o; o = swn_al(o + 1);
     y->bx = o; o = swn_al(o + (size_t)g->L * 2 * g->H);
+    y->bxr = o; o = swn_al(o + (size_t)g->L * 2 * g->H);
     y->cb = o; o = swn_al(o + g->H);
     y->cv = o; y->cc = o; y->ct = o;
     if (g->kind == SWN_KIND_LAPLACE) {

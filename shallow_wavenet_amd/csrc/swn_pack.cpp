@@ -51,7 +51,7 @@ extern "C" int swn_layout_offsets(const swn_net_desc* d, size_t* out, int n) {
     SwnLayout y; swn_make_layout(&g, &y);
     const size_t v[] = {y.scale_w, y.scale_b, y.aux_w[0], y.aux_w[1], y.aux_w[2], y.aux_w[3], y.aux_b[0], y.aux_b[1],
                         y.aux_b[2], y.aux_b[3], y.wx, y.wxa, y.wup, y.bup, y.bx, y.cb, y.cv, y.cc, y.ct, y.wd, y.bd,
-                        y.wsk, y.bsk, y.w1, y.b1, y.w2, y.b2, y.total};
+                        y.wsk, y.bsk, y.w1, y.b1, y.w2, y.b2, y.total, y.bxr};
     const int cnt = (int)(sizeof(v) / sizeof(v[0]));
     if (!out || n < cnt) return SWN_E_BADARG;
     for (int i = 0; i < cnt; ++i) out[i] = v[i];
@@ -146,6 +146,7 @@ extern "C" int swn_pack_params(const swn_net_desc* d, const float* const* t, int
                     out[y.wx + ((size_t)(l * seg + s) * H2 + o) * g.A0p + c] = v;
                 }
             out[y.bx + (size_t)l * H2 + o] = (float)(bo + (double)bup[0] * ws);
+            out[y.bxr + (size_t)l * H2 + o] = (float)bo;
             if (g.audio_in)
                 for (int q = 0; q < Q; ++q)
                     out[y.wxa + ((size_t)l * Q + q) * H2 + o] = w[(size_t)o * A + g.A0 + q];

@@ -26,6 +26,7 @@ struct FwdArgs {
     const void* audio;
     float* hs;        // (B, L+1, H, Tp)
     int B, Tf, Tp, coff;   // coff: conditioning offset (seg for laplace, 1 for softmax)
+    const float* gx;       // dropout mode: (B, L, 2H, Tp) sample-rate in_x products of the masked conditioning, or null
 };
 
 // ---- input layer -------------------------------------------------------------------------------
@@ -69,7 +70,7 @@ __global__ __launch_bounds__(256) void tf_input_kernel(const FwdArgs a) {
 // GEMM over Kd = K*H with the B operand = K dilated shifts of h_{l-1}; BK = 16; thread = 4 positions
 // x (2 gate + 2 candidate rows); fused epilogue writes h_l.
 template <int KIND>
-__global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const int l) {
+__global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const int l, const float* __restrict__ in_mul) {
     __shared__ float As[16][64 + 4];      // [k][tile row]: rows 0..31 gate, 32..63 candidate
     __shared__ float Bs[16][64 + 4];      // [k][position]
     const SwnGeom& g = a.g;
@@ -99,7 +100,9 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
             const int kd = k0 + kk;
             const int tap = kd / Hp, i = kd - tap * Hp;
             const int ts = t0 + tt - (K - 1 - tap) * dil;
-            Bs[kk][tt] = (kd < Kd && i < H && ts >= 0 && t0 + tt < a.Tp) ? hprev[(size_t)i * a.Tp + ts] : 0.f;
+            float v = (kd < Kd && i < H && ts >= 0 && t0 + tt < a.Tp) ? hprev[(size_t)i * a.Tp + ts] : 0.f;
+            if (in_mul && v != 0.f) v *= in_mul[((size_t)b * H + i) * a.Tp + ts];       // input = dropped output of layer l-1
+            Bs[kk][tt] = v;
         }
         __syncthreads();
 #pragma unroll
@@ -130,15 +133,22 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
             const int t = t0 + 4 * tx + j;
             hv[j] = 0.f;
             if (t >= a.Tp) continue;
-            float gz = bxz, gc = bxc;
-            for (int s = 0; s < seg; ++s) {
-                const int tt = t + s + a.coff;
-                int f = tt / g.U; const int jj = tt - f * g.U;
-                f = f < a.Tf ? f : a.Tf - 1;
-                const float w = P[a.y.wup + jj];
-                const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
-                gz = fmaf(w, cr[o], gz);
-                gc = fmaf(w, cr[H + o], gc);
+            float gz, gc;
+            if (a.gx) {      // dropout mode: in_x evaluated at sample rate on the masked conditioning
+                const float* gr = a.gx + (((size_t)b * g.L + l) * H2) * a.Tp + t;
+                gz = gr[(size_t)o * a.Tp] + P[a.y.bxr + (size_t)l * H2 + o];
+                gc = gr[(size_t)(H + o) * a.Tp] + P[a.y.bxr + (size_t)l * H2 + H + o];
+            } else {
+                gz = bxz; gc = bxc;
+                for (int s = 0; s < seg; ++s) {
+                    const int tt = t + s + a.coff;
+                    int f = tt / g.U; const int jj = tt - f * g.U;
+                    f = f < a.Tf ? f : a.Tf - 1;
+                    const float w = P[a.y.wup + jj];
+                    const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+                    gz = fmaf(w, cr[o], gz);
+                    gc = fmaf(w, cr[H + o], gc);
+                }
             }
             if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
                 int idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q;
@@ -148,7 +158,8 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
             }
             const float z = sigm(gz * (acc[r][j] + bz));
             const float c = tanhf(gc * (acc[2 + r][j] + bc));
-            hv[j] = (1.f - z) * c + z * hprev[(size_t)o * a.Tp + t];
+            const float hin = hprev[(size_t)o * a.Tp + t] * (in_mul ? in_mul[((size_t)b * H + o) * a.Tp + t] : 1.f);
+            hv[j] = (1.f - z) * c + z * hin;
         }
         float* dst = hnext + (size_t)o * a.Tp + t0 + 4 * tx;
         if (t0 + 4 * tx + 3 < a.Tp && (a.Tp & 3) == 0) {
@@ -266,13 +277,38 @@ extern "C" size_t swn_forward_work_floats(const swn_net_desc* d, int batch, int 
     return r64((size_t)batch * (g.L + 1) * g.H * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * g.O1 * Tp);
 }
 
-extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const float* cond, const void* audio,
-                           int batch, int n_frames, float* work, float* out, float* hs, void* stream_) {
+namespace {
+
+// masked, upsampled conditioning for the dropout mode: xm[b][c][u] = drop_x[b][c][u] * (C[b][c][f] * w_up[j] + b_up)
+// with u + coff = f*U + j   (cswnv_shift1.py:193-195, dswnv.py:252-254)
+__global__ __launch_bounds__(256) void xm_fwd_kernel(const float* __restrict__ C, const float* __restrict__ P, size_t wup, size_t bup,
+                                                     const float* __restrict__ drop_x, float* __restrict__ xm,
+                                                     int A0, int Tf, int U, int coff, int Tx) {
+    const int u = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (u >= Tx) return;
+    const int tt = u + coff, f = tt / U, j = tt - f * U;
+    const size_t o = ((size_t)b * A0 + c) * Tx + u;
+    xm[o] = drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]);
+}
+
+}  // namespace
+
+// sample-rate in_x of every layer over the masked conditioning (csrc/swn_train.hip: generic time GEMM)
+int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
+                          int B, int Tx, int Tp, hipStream_t st);
+
+namespace {
+
+int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, const float* fe_work, const void* audio,
+                 int batch, int n_frames, const float* drop_x, const float* const* drop_h, float* work, float* out,
+                 float* hs, void* stream_, const char* where) {
     FwdArgs a;
     int rc = swn_make_geom(d, &a.g);
     if (rc < 0) return rc;
     const SwnGeom& g = a.g;
-    if (!packed || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+    const bool drop = drop_x != nullptr;
+    if (!packed || (!drop && !cond) || (drop && (!fe_work || !drop_h)) || !audio || !work || !out || batch < 1 ||
+        batch > 65535 || n_frames < 1) return SWN_E_BADARG;
     swn_make_layout(&a.g, &a.y);
     const long T = (long)n_frames * g.U;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
@@ -285,6 +321,21 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     float* o1b = skipb + r64((size_t)batch * g.S * Tp);
     a.P = packed; a.cond = cond; a.audio = audio; a.hs = hbuf; a.B = batch; a.Tf = n_frames; a.Tp = (int)Tp;
     a.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    a.gx = nullptr;
+    if (drop) {
+        // work tail: xm (B, A0, Tx) | gx (B, L, 2H, Tp)
+        const int Tx = (int)(T - a.coff);
+        float* xm = o1b + r64((size_t)batch * g.O1 * Tp);
+        float* gx = xm + r64((size_t)batch * g.A0 * Tx);
+        size_t fe_off = (size_t)g.n_aux;                         // frame-rate activations: scaled | conv_aux layers
+        for (int i = 0; i + 1 < g.auxl; ++i) fe_off += g.aux_cout[i];
+        const float* C = fe_work + fe_off * (size_t)batch * n_frames;
+        hipLaunchKernelGGL(xm_fwd_kernel, dim3((Tx + 255) / 256, g.A0, batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
+                           drop_x, xm, g.A0, n_frames, g.U, a.coff, Tx);
+        rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st);
+        if (rc < 0) return rc;
+        a.gx = gx;
+    }
     const int tb64 = (int)((Tp + 63) / 64);
     {
         dim3 grid((unsigned)((Tp + 255) / 256), g.H < 16 ? g.H : 16, batch);
@@ -293,11 +344,12 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     }
     for (int l = 0; l < g.L; ++l) {
         dim3 grid(tb64, (g.H + 31) / 32, batch);
-        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a, l);
-        else hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a, l);
+        const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;      // layer l-1's output was dropped
+        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a, l, in_mul);
+        else hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a, l, in_mul);
     }
     const size_t hstride = (size_t)(g.L + 1) * g.H * Tp;
-    // skip: one GEMM over the L concatenated hidden states (requires Hp == H, i.e. H % 4 == 0)
+    // skip: one GEMM over the L concatenated (undropped) hidden states (requires Hp == H, i.e. H % 4 == 0)
     if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.S + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.wsk, g.L * g.Hp, packed + a.y.bsk, hbuf + (size_t)g.H * Tp, hstride,
@@ -308,7 +360,32 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.NO + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.w2, g.O1p, packed + a.y.b2, o1b, (size_t)g.O1 * Tp,
                        out, (size_t)g.NO * Tp, g.NO, g.O1, (int)Tp, 0);
-    return swn_launch_status("swn_forward");
+    return swn_launch_status(where);
+}
+
+}  // namespace
+
+extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const float* cond, const void* audio,
+                           int batch, int n_frames, float* work, float* out, float* hs, void* stream_) {
+    return forward_impl(d, packed, cond, nullptr, audio, batch, n_frames, nullptr, nullptr, work, out, hs, stream_, "swn_forward");
+}
+
+extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    const size_t base = swn_forward_work_floats(d, batch, n_frames);
+    if (!base) return 0;
+    const long T = (long)n_frames * g.U;
+    const int coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
+    return base + r64((size_t)batch * g.A0 * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp);
+}
+
+extern "C" int swn_forward_drop(const swn_net_desc* d, const float* packed, const float* fe_work, const void* audio,
+                                int batch, int n_frames, const float* drop_x, const float* const* drop_h,
+                                float* work, float* out, float* hs, void* stream_) {
+    if (!drop_x) return SWN_E_BADARG;
+    return forward_impl(d, packed, nullptr, fe_work, audio, batch, n_frames, drop_x, drop_h, work, out, hs, stream_,
+                        "swn_forward_drop");
 }
 
 extern "C" int swn_laplace_head(const swn_net_desc* d, const float* out, int batch, int tp, float* mu, float* b,

@@ -24,6 +24,10 @@ struct TimeGemm {
     float* Y; long y_sb, y_sm;                      // Y[b][m][t], t contiguous
     const float* mask; long k_sb, k_sm;             // optional relu mask (same indexing as Y): keep where mask > 0
     int M, taps, KC, T, sgn, center, dil, accumulate;
+    // optional (appended, zero = off): multiplicative masks for dropout, and a separate valid length of X
+    const float* xmul; long xm_sb, xm_sc;           // X[b][c][t] is read as X * xmul[b][c][t]
+    const float* ymul; long ym_sb, ym_sm;           // the result is scaled by ymul[b][m][t] before it is stored / added
+    int XT;                                         // X is valid on [0, XT) (0: same as T)
 };
 
 // 64(m) x 64(t) tile, BK = 16 over k = (tap, c); thread = 4 x 4.
@@ -50,7 +54,10 @@ __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
             if (k < Kd) {
                 const int tap = k / g.KC, c = k - tap * g.KC;
                 const int ts = t0 + tt + g.sgn * (tap - g.center) * g.dil;
-                if (ts >= 0 && ts < g.T && t0 + tt < g.T) v = Xb[c * g.x_sc + ts * g.x_st];
+                if (ts >= 0 && ts < (g.XT ? g.XT : g.T) && t0 + tt < g.T) {
+                    v = Xb[c * g.x_sc + ts * g.x_st];
+                    if (g.xmul) v *= g.xmul[(size_t)b * g.xm_sb + (size_t)c * g.xm_sc + ts];
+                }
             }
             Bs[kk][tt] = v;
         }
@@ -77,6 +84,7 @@ __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
             if (t >= g.T) continue;
             float v = acc[r][j];
             if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
+            if (g.ymul) v *= g.ymul[(size_t)b * g.ym_sb + (size_t)m * g.ym_sm + t];
             float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
             *y = g.accumulate ? *y + v : v;
         }
@@ -89,6 +97,8 @@ struct ReduceGemm {
     float* G; long g_sm, g_stap, g_sc;              // G(m, tap, c)  += ...
     float* gb;                                      // optional: gb[m] += sum_{b,t} P
     int M, taps, KC, T, sgn, center, dil, TS;       // TS: time positions per block
+    const float* qmul; long qm_sb, qm_sc;           // optional: Q[b][c][t] is read as Q * qmul[b][c][t]
+    int QT;                                         // Q is valid on [0, QT) (0: same as T)
 };
 
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
@@ -117,7 +127,10 @@ __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
             if (t < tend && nc < Nc) {
                 const int tap = nc / g.KC, c = nc - tap * g.KC;
                 const int tsrc = t + g.sgn * (tap - g.center) * g.dil;
-                if (tsrc >= 0 && tsrc < g.T) v = Qb[c * g.q_sc + tsrc * g.q_st];
+                if (tsrc >= 0 && tsrc < (g.QT ? g.QT : g.T)) {
+                    v = Qb[c * g.q_sc + tsrc * g.q_st];
+                    if (g.qmul) v *= g.qmul[(size_t)b * g.qm_sb + (size_t)c * g.qm_sc + tsrc];
+                }
             }
             Qs[kk][nn] = v;
         }
@@ -158,6 +171,9 @@ struct GateBwd {
     const float* P; const float* cond; const void* audio;
     const float* hs; float* dhs; float* a_da; float* dgx;
     int B, Tf, Tp, coff, l;
+    // dropout mode (appended, null = off)
+    const float* gx;       // (B, L, 2H, Tp) sample-rate in_x products (no bias) of the masked conditioning
+    const float* in_mul;   // (B, H, Tp) mask on this layer's INPUT h_{l-1}: it was the dropped output of layer l-1
 };
 
 template <int KIND>
@@ -168,19 +184,27 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     const int H = g.H, H2 = 2 * g.H, l = a.l, seg = g.seg;
     const float* P = a.P;
     const size_t hb = ((size_t)b * (g.L + 1)) * H * a.Tp;
-    const float hprev = a.hs[hb + ((size_t)l * H + o) * a.Tp + t];
+    const float im = a.in_mul ? a.in_mul[((size_t)b * H + o) * a.Tp + t] : 1.f;
+    const float hprev = a.hs[hb + ((size_t)l * H + o) * a.Tp + t] * im;
     const float dh = a.dhs[hb + ((size_t)(l + 1) * H + o) * a.Tp + t];
     float* az = a.a_da + ((size_t)b * H2 + o) * a.Tp + t;
     float* ac = a.a_da + ((size_t)b * H2 + H + o) * a.Tp + t;
-    float gz = P[a.y.bx + (size_t)l * H2 + o], gc = P[a.y.bx + (size_t)l * H2 + H + o];
-    const float* condb = a.cond + (size_t)b * a.Tf * g.N;
-    for (int s = 0; s < seg; ++s) {
-        const int tt = t + s + a.coff;
-        int f = tt / g.U; const int jj = tt - f * g.U;
-        f = f < a.Tf ? f : a.Tf - 1;
-        const float w = P[a.y.wup + jj];
-        const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
-        gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
+    float gz, gc;
+    if (a.gx) {
+        const float* gr = a.gx + (((size_t)b * g.L + l) * H2) * a.Tp + t;
+        gz = gr[(size_t)o * a.Tp] + P[a.y.bxr + (size_t)l * H2 + o];
+        gc = gr[(size_t)(H + o) * a.Tp] + P[a.y.bxr + (size_t)l * H2 + H + o];
+    } else {
+        gz = P[a.y.bx + (size_t)l * H2 + o]; gc = P[a.y.bx + (size_t)l * H2 + H + o];
+        const float* condb = a.cond + (size_t)b * a.Tf * g.N;
+        for (int s = 0; s < seg; ++s) {
+            const int tt = t + s + a.coff;
+            int f = tt / g.U; const int jj = tt - f * g.U;
+            f = f < a.Tf ? f : a.Tf - 1;
+            const float w = P[a.y.wup + jj];
+            const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+            gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
+        }
     }
     if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
         int idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q; idx = idx < 0 ? idx + g.Q : idx;
@@ -194,7 +218,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     *az = dz * gz; *ac = dc * gc;                           // da
     a.dgx[((size_t)b * H2 + o) * a.Tp + t] = dz * sz;
     a.dgx[((size_t)b * H2 + H + o) * a.Tp + t] = dc * sc;
-    a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z;   // highway path
+    a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z * im;   // highway path (through the input's dropout mask)
 }
 
 // ---- hoisted conditioning backward, two orientations of the same (frame x tap) product:
@@ -321,15 +345,61 @@ extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int
            2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames);
 }
 
-extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
-                            const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
-                            const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
+namespace {
+
+// dropout mode, conditioning side: dx = dxm * drop_x ; dC[b][c][f] = sum_j dx[c][f*U+j-coff] w_up[j] ;
+// g w_up[j] += sum dx * C ; g b_up += sum dx          (backward of xm_fwd_kernel, csrc/swn_stack.hip)
+__global__ __launch_bounds__(256) void xm_bwd_kernel(const float* __restrict__ dxm, const float* __restrict__ drop_x,
+                                                     const float* __restrict__ C, const float* __restrict__ P, size_t wup,
+                                                     float* __restrict__ dC, float* __restrict__ gwup, float* __restrict__ gbup,
+                                                     int A0, int Tf, int U, int coff, int Tx) {
+    __shared__ float red[256];
+    const int j = threadIdx.x, f = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
+    const int u = f * U + j - coff;
+    float dx = 0.f;
+    if (j < U && u >= 0 && u < Tx) { const size_t o = ((size_t)b * A0 + c) * Tx + u; dx = dxm[o] * drop_x[o]; }
+    const float cv = C[((size_t)b * A0 + c) * Tf + f];
+    if (j < U && dx != 0.f) atomicAdd(gwup + j, dx * cv);
+    red[j] = j < U ? dx * P[wup + j] : 0.f;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) { if (j < sft) red[j] += red[j + sft]; __syncthreads(); }
+    if (j == 0) dC[((size_t)b * A0 + c) * Tf + f] = red[0];
+    __syncthreads();
+    red[j] = dx;
+    __syncthreads();
+    for (int sft = 128; sft > 0; sft >>= 1) { if (j < sft) red[j] += red[j + sft]; __syncthreads(); }
+    if (j == 0 && red[0] != 0.f) atomicAdd(gbup, red[0]);
+}
+
+}  // namespace
+
+int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
+                          int B, int Tx, int Tp, hipStream_t st) {
+    const int H2 = 2 * g.H;
+    for (int l = 0; l < g.L; ++l) {   // gx[b][l][o][t] = sum_{s,c} W[l][o][c*seg+s] xm[b][c][t+s]
+        TimeGemm t = {packed + y.wx + (size_t)l * g.seg * H2 * g.A0p, g.A0p, (long)H2 * g.A0p, 1,
+                      xm, (long)g.A0 * Tx, Tx, 1, gx + (size_t)l * H2 * Tp, (long)g.L * H2 * Tp, Tp, nullptr, 0, 0,
+                      H2, g.seg, g.A0, Tp, 1, 0, 1, 0};
+        t.XT = Tx;
+        launch_time(t, B, st);
+    }
+    return SWN_OK;
+}
+
+namespace {
+
+int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
+                  const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
+                  const float* drop_x, const float* const* drop_h,
+                  const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_,
+                  const char* where) {
     GateBwd ga;
     int rc = swn_make_geom(d, &ga.g);
     if (rc < 0) return rc;
     const SwnGeom& g = ga.g;
-    if (!packed || !aux || !cond || !fe_work || !audio || !fwd_work || !grad_out || !work || !gpacked ||
-        batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+    const bool drop = drop_x != nullptr;
+    if (!packed || !aux || (!drop && !cond) || (drop && !drop_h) || !fe_work || !audio || !fwd_work || !grad_out || !work ||
+        !gpacked || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
     if (g.Hp != g.H || g.K > 8 || g.U > 256) return SWN_E_UNSUPPORTED;
     swn_make_layout(&ga.g, &ga.y);
     const SwnLayout& y = ga.y;
@@ -352,6 +422,13 @@ extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const fl
     float* dgx = a_da + r64((size_t)B * H2 * Tp);
     float* dcond = dgx + r64((size_t)B * H2 * Tp);
     float* dfe = dcond + r64((size_t)B * n_frames * g.N);
+    // dropout mode: forward work tail = xm | gx (swn_forward_drop); scratch tail = dxm
+    const int coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    const int Tx = (int)(T - coff);
+    size_t fe_tot = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fe_tot += g.aux_cout[i];
+    const float* xm = r1 + r64((size_t)B * O1 * Tp);
+    const float* gx = xm + r64((size_t)B * g.A0 * Tx);
+    float* dxm = dfe + r64(fe_tot * B * n_frames);
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     if (hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     const long hsb = (long)(L + 1) * H * Tp;
@@ -383,13 +460,18 @@ extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const fl
     }
     // ---- layers, last to first
     ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx;
-    ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
+    ga.gx = drop ? gx : nullptr;
     for (int l = L - 1; l >= 0; --l) {
         ga.l = l;
+        // dropout mode: this layer's input is h_{l-1} times the mask drawn for layer l-1's output (cswnv_shift1.py:269-273)
+        const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;
+        ga.in_mul = in_mul;
         const float* Wd = packed + y.wd + (size_t)l * H2 * g.K * g.Hp;                 // [o2][tap][i]
         {   // a = Wd (*) h_{l-1}   (bias added in the gate kernel)
             TimeGemm t = {Wd, (long)g.K * g.Hp, g.Hp, 1, hs + (size_t)l * H * Tp, hsb, Tp, 1, a_da, (long)H2 * Tp, Tp, nullptr, 0, 0,
                           H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
+            t.xmul = in_mul; t.xm_sb = (long)H * Tp; t.xm_sc = Tp;
             launch_time(t, B, st);
         }
         {
@@ -401,15 +483,34 @@ extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const fl
             ReduceGemm r = {a_da, (long)H2 * Tp, Tp, 1, hs + (size_t)l * H * Tp, hsb, Tp, 1,
                             gpacked + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, gpacked + y.bd + (size_t)l * H2,
                             H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
+            r.qmul = in_mul; r.qm_sb = (long)H * Tp; r.qm_sc = Tp;
             launch_reduce(r, B, st);
         }
         {   // dh_{l-1} += Wd^T (*) da  (taps shifted forward): A(m=i, tap, c=o2) = Wd[o2][tap][i]
             TimeGemm t = {Wd, 1, g.Hp, (long)g.K * g.Hp, a_da, (long)H2 * Tp, Tp, 1, dhs + (size_t)l * H * Tp, hsb, Tp, nullptr, 0, 0,
                           H, g.K, H2, Tp, -1, g.K - 1, g.dil[l], 1};
+            t.ymul = in_mul; t.ym_sb = (long)H * Tp; t.ym_sm = Tp;
             launch_time(t, B, st);
         }
-        hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 255) / 256, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx);
-        hipLaunchKernelGGL(wup_bwd_kernel, dim3(n_frames, B), dim3(256), 0, st, ga, gpacked + y.wup);
+        if (!drop) {
+            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 255) / 256, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx);
+            hipLaunchKernelGGL(wup_bwd_kernel, dim3(n_frames, B), dim3(256), 0, st, ga, gpacked + y.wup);
+        } else {
+            const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
+            {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
+                ReduceGemm r = {dgx, (long)H2 * Tp, Tp, 1, xm, (long)g.A0 * Tx, Tx, 1,
+                                gpacked + y.wx + (size_t)l * g.seg * H2 * g.A0p, g.A0p, (long)H2 * g.A0p, 1,
+                                gpacked + y.bxr + (size_t)l * H2, H2, g.seg, g.A0, Tp, 1, 0, 1, 0};
+                r.QT = Tx;
+                launch_reduce(r, B, st);
+            }
+            {   // dxm[c][u] (+)= sum_{s,o} W[l][o][c*seg+s] dgx[o][u-s]
+                TimeGemm t = {Wx, 1, (long)H2 * g.A0p, g.A0p, dgx, (long)H2 * Tp, Tp, 1, dxm, (long)g.A0 * Tx, Tx, nullptr, 0, 0,
+                              g.A0, g.seg, H2, Tx, -1, 0, 1, l == L - 1 ? 0 : 1};
+                t.XT = Tp;
+                launch_time(t, B, st);
+            }
+        }
     }
     // ---- input layer
     if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_LAPLACE>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
@@ -424,6 +525,10 @@ extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const fl
         chn[0] = g.n_aux; act[0] = p; dact[0] = q; p += bt * g.n_aux; q += bt * g.n_aux;
         for (int i = 0; i < g.auxl; ++i) { chn[i + 1] = g.aux_cout[i]; act[i + 1] = p; dact[i + 1] = q; p += bt * g.aux_cout[i]; q += bt * g.aux_cout[i]; }
         const float* C = act[g.auxl];
+        if (drop) {
+            hipLaunchKernelGGL(xm_bwd_kernel, dim3(n_frames, g.A0, B), dim3(256), 0, st, dxm, drop_x, C, packed, y.wup,
+                               dact[g.auxl], gpacked + y.wup, gpacked + y.bup, g.A0, n_frames, g.U, coff, Tx);
+        } else
         {   // dC[b][c][f] = sum_n Wx[n][c] dcond[b][f][n] ; gWx[n][c] += sum_{b,f} dcond[b][f][n] C[b][c][f]
             TimeGemm t = {packed + y.wx, 1, 0, g.A0p, dcond, (long)n_frames * g.N, 1, g.N, dact[g.auxl], (long)g.A0 * n_frames, n_frames,
                           nullptr, 0, 0, g.A0, 1, g.N, n_frames, 1, 0, 1, 0};
@@ -451,7 +556,33 @@ extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const fl
             launch_reduce(r, B, st);
         }
     }
-    return swn_launch_status("swn_backward");
+    return swn_launch_status(where);
+}
+
+}  // namespace
+
+extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
+                            const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
+                            const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
+    return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, hs_opt, nullptr, nullptr, grad_out, batch, n_frames,
+                         work, gpacked, stream_, "swn_backward");
+}
+
+extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0) return 0;
+    const size_t base = swn_backward_work_floats(d, batch, n_frames);
+    if (!base) return 0;
+    const long T = (long)n_frames * g.U;
+    return base + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg)));
+}
+
+extern "C" int swn_backward_drop(const swn_net_desc* d, const float* packed, const float* aux, const float* fe_work,
+                                 const void* audio, const float* fwd_work, const float* hs_opt, const float* drop_x,
+                                 const float* const* drop_h, const float* grad_out, int batch, int n_frames, float* work,
+                                 float* gpacked, void* stream_) {
+    if (!drop_x) return SWN_E_BADARG;
+    return backward_impl(d, packed, aux, nullptr, fe_work, audio, fwd_work, hs_opt, drop_x, drop_h, grad_out, batch, n_frames,
+                         work, gpacked, stream_, "swn_backward_drop");
 }
 
 extern "C" int swn_laplace_head_backward(const swn_net_desc* d, const float* raw, int batch, int tp, const float* gmu,

@@ -30,7 +30,8 @@ def unfold_packed_grads(cfg: NetConfig, gp: torch.Tensor, params: Dict[str, torc
         cin, cout = n * k ** i, n * k ** (i + 1)
         g[f"conv_aux.conv.{i}.weight"] = sec(f"aux_w{i}", cout * cin * k).view(cout, cin, k)
         g[f"conv_aux.conv.{i}.bias"] = sec(f"aux_b{i}", cout)
-    gbx = sec("bx", L * H2).view(L, H2)
+    gbx = sec("bx", L * H2).view(L, H2)             # hoisted mode: d(b_inx + b_up * sum W)
+    gbt = gbx + sec("bxr", L * H2).view(L, H2)      # + dropout mode: d(b_inx) directly
     gwx = sec("wx", L * seg * H2 * A0p).view(L, seg, H2, A0p)[..., :A0]            # [l][s][o][c]
     b_up = params["upsampling.conv.bias"].reshape(())
     g["upsampling.conv.weight"] = sec("wup", U).view(1, 1, 1, U)
@@ -44,7 +45,7 @@ def unfold_packed_grads(cfg: NetConfig, gp: torch.Tensor, params: Dict[str, torc
     else:
         weff = [params[f"in_x.{l}.weight"][:, : A0 * seg, 0] for l in range(L)]
     wsum = torch.stack([w.sum(1) for w in weff])                                                  # [l][o]
-    g["upsampling.conv.bias"] = (gbx * wsum).sum().reshape(1)
+    g["upsampling.conv.bias"] = (gbx * wsum).sum().reshape(1) + sec("bup", 1)
     for l in range(L):
         gw = gwx[l].permute(1, 2, 0).reshape(H2, A0 * seg) + gbx[l][:, None] * b_up        # [o][c*seg+s]
         if cfg.kind == "softmax" and cfg.audio_in_flag:
@@ -52,10 +53,10 @@ def unfold_packed_grads(cfg: NetConfig, gp: torch.Tensor, params: Dict[str, torc
         if c2d:
             w_in = params[f"in_x.{l}.weight"][:, :, 0]
             g["aux_conv2d.weight"] += (w_in.t() @ gw).reshape(A0, A0, seg, 1)
-            g["aux_conv2d.bias"] += w_in.t() @ gbx[l]
-            gw = gw @ w2f.t() + gbx[l][:, None] * b2[None, :]
+            g["aux_conv2d.bias"] += w_in.t() @ gbt[l]
+            gw = gw @ w2f.t() + gbt[l][:, None] * b2[None, :]
         g[f"in_x.{l}.weight"] = gw.unsqueeze(2)
-        g[f"in_x.{l}.bias"] = gbx[l]
+        g[f"in_x.{l}.bias"] = gbt[l]
     gcb = sec("cb", H)
     wc = params["causal.conv.weight"]                                            # (H, Cin, K)
     if cfg.kind == "laplace":
@@ -100,7 +101,8 @@ class StackFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, module, aux, audio, *params):
         net: HipNet = module._engine()
-        raw, saved = net.forward_train(aux, audio)
+        raw, saved = net.forward_train(aux, audio, drop=getattr(module, "_pending_drop", None))
+        module._pending_drop = None
         ctx.net, ctx.saved, ctx.module = net, saved, module
         ctx.names = [k for k, _ in module.named_parameters()]
         return raw

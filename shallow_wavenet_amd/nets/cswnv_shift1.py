@@ -105,12 +105,18 @@ class CSWNV(EngineMixin, nn.Module):
         """aux (B, n_aux, Tf), audio (B, 1, Tf*U - seg) -> the reference's tuples:
         lpc>0: (mu, b, log_b, a) | clip: (mu, b_noclip, b, log_b, a); lpc==0 drops `a`;
         seg==1 and lpc==0 returns 2-D (B, T') tensors (cswnv_shift1.py:228-267)."""
-        if do and self.do_prob > 0:
-            raise NotImplementedError("dropout (do=True) is a training feature that is not built yet")
         net = self._engine()
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        # nn.Dropout only acts in training mode (model.train(), train_cswnv...py:716); masks are drawn on the host
+        # in the reference's order and handed to the dropout-mode kernels
+        drop = None
+        if do and self.do_prob > 0 and self.training:
+            if self.dilation_depth * self.dilation_repeat <= 2:
+                raise NotImplementedError("dropout for a <=2-layer stack (cswnv_shift1.py:221-223) is not built")
+            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob)
+        if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             # training: HIP forward + HIP backward behind autograd Functions (nets/_autograd.py)
             from shallow_wavenet_amd.nets._autograd import LaplaceHeadFunction, StackFunction
+            self._pending_drop = drop
             raw = StackFunction.apply(self, aux, audio, *self.parameters())
             mu, b, log_b, a, b_clip, log_b_clip, flag = LaplaceHeadFunction.apply(net, raw, clip)
             a = a if self.lpc > 0 else None

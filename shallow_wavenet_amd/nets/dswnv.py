@@ -126,12 +126,14 @@ class DSWNV(EngineMixin, nn.Module):
     def forward(self, audio, aux, do=False, last=False):
         """audio: one-hot (B, Q, Tf*U-1) as the training script builds it (or (B, Tf*U-1) classes),
         aux (B, n_aux, Tf) -> logits (B, Tf*U-1, Q)."""
-        if do and self.do_prob > 0:
-            raise NotImplementedError("dropout (do=True) is a training feature that is not built yet")
         net = self._engine()
         idx = self._indices(audio, self.n_quantize)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+        drop = None
+        if do and self.do_prob > 0 and self.training:          # nn.Dropout acts in training mode only
+            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob)
+        if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             from shallow_wavenet_amd.nets._autograd import StackFunction
+            self._pending_drop = drop
             raw = StackFunction.apply(self, aux, idx, *self.parameters())
         else:
             raw, _ = net.forward(aux, idx)

@@ -53,7 +53,7 @@ def pack_state_dict(cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Te
 
 LAYOUT_FIELDS = ("scale_w", "scale_b", "aux_w0", "aux_w1", "aux_w2", "aux_w3", "aux_b0", "aux_b1", "aux_b2", "aux_b3",
                  "wx", "wxa", "wup", "bup", "bx", "cb", "cv", "cc", "ct", "wd", "bd", "wsk", "bsk", "w1", "b1", "w2",
-                 "b2", "total")
+                 "b2", "total", "bxr")
 
 
 def layout_offsets(cfg: NetConfig) -> Dict[str, int]:
@@ -201,8 +201,11 @@ class HipNet:
 
 
     # ------------------------------------------------------------------ training (fp32)
-    def forward_train(self, aux: torch.Tensor, audio: torch.Tensor):
-        """forward that keeps what swn_backward needs: returns (raw, saved) ."""
+    def forward_train(self, aux: torch.Tensor, audio: torch.Tensor, drop=None):
+        """forward that keeps what swn_backward needs: returns (raw, saved).  `drop` = (drop_x, [drop_h per layer or
+        None]) switches to the dropout-mode kernels (noise.dropout_masks draws them in the reference's order)."""
+        if drop is not None:
+            return self._forward_train_drop(aux, audio, drop)
         cfg = self.cfg
         aux = aux.to(self.device, torch.float32).contiguous()
         cond = self.frontend(aux)
@@ -220,11 +223,55 @@ class HipNet:
                                             _ptr(out), _ptr(None), _stream_ptr(self.device)), "forward")
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
 
+    def _drop_args(self, drop):
+        drop_x, drop_h = drop
+        cfg = self.cfg
+        drop_x = drop_x.to(self.device, torch.float32).contiguous()
+        drop_h = [None if m is None else m.to(self.device, torch.float32).contiguous() for m in drop_h]
+        if len(drop_h) != cfg.L:
+            raise ValueError("drop_h needs one entry (mask or None) per layer")
+        ptrs = (ctypes.c_void_p * cfg.L)(*[_ptr(m) for m in drop_h])
+        return drop_x, drop_h, ptrs
+
+    def _forward_train_drop(self, aux, audio, drop):
+        cfg = self.cfg
+        aux = aux.to(self.device, torch.float32).contiguous()
+        self.frontend(aux)
+        fe_work = self._last_frontend_work
+        soft = cfg.kind == "softmax"
+        B, Tf = aux.shape[0], aux.shape[2]
+        T = Tf * cfg.U
+        Tp = T - 1 if soft else T - 2 * cfg.seg + 1
+        coff = 1 if soft else cfg.seg
+        audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
+        drop_x, drop_h, ptrs = self._drop_args(drop)
+        if tuple(drop_x.shape) != (B, cfg.A0, T - coff) or any(m is not None and tuple(m.shape) != (B, cfg.H, Tp) for m in drop_h):
+            raise ValueError("dropout mask shapes must be (B, A0, T-coff) and (B, H, Tp)")
+        d = ctypes.byref(self.desc)
+        work = torch.empty(self.lib.swn_forward_drop_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib.swn_forward_drop(d, _ptr(self.packed), _ptr(fe_work), _ptr(audio), B, Tf, _ptr(drop_x),
+                                                 ctypes.cast(ptrs, ctypes.c_void_p), _ptr(work), _ptr(out), _ptr(None),
+                                                 _stream_ptr(self.device)), "forward_drop")
+        return out, dict(aux=aux, cond=None, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf,
+                         drop=(drop_x, drop_h, ptrs))
+
     def backward(self, saved, grad_raw: torch.Tensor) -> torch.Tensor:
         """gradient of the loss wrt the packed parameter buffer, given d loss / d raw (B, n_out, Tp)."""
         L, d = self.lib, ctypes.byref(self.desc)
         B, Tf = saved["B"], saved["Tf"]
         grad_raw = grad_raw.to(self.device, torch.float32).contiguous()
+        if saved.get("drop") is not None:
+            drop_x, drop_h, ptrs = saved["drop"]
+            work = torch.empty(L.swn_backward_drop_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+            gp = torch.empty_like(self.packed)
+            with torch.cuda.device(self.device):
+                _lib.check(L.swn_backward_drop(d, _ptr(self.packed), _ptr(saved["aux"]), _ptr(saved["fe_work"]),
+                                               _ptr(saved["audio"]), _ptr(saved["work"]), _ptr(None), _ptr(drop_x),
+                                               ctypes.cast(ptrs, ctypes.c_void_p), _ptr(grad_raw), B, Tf, _ptr(work),
+                                               _ptr(gp), _stream_ptr(self.device)), "backward_drop")
+            return gp
         work = torch.empty(L.swn_backward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
         gp = torch.empty_like(self.packed)
         with torch.cuda.device(self.device):

@@ -94,6 +94,9 @@ def test_pack_layout_known_answers():
     o = al(o + L * 2 * H)
     want = sd["in_x.2.bias"][5] + sd["upsampling.conv.bias"][0] * sd["in_x.2.weight"][5].astype(np.float64).sum()
     assert abs(packed[o_bx + 2 * 2 * H + 5] - want) < 1e-6
+    o_bxr = o                                  # raw in_x bias (dropout mode evaluates in_x at sample rate)
+    o = al(o + L * 2 * H)
+    assert packed[o_bxr + 2 * 2 * H + 5] == sd["in_x.2.bias"][5]
     o = al(o + H)
     o_cv = o
     o = al(o + K * H)

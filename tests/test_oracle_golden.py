@@ -24,8 +24,8 @@ def _params(cfg, d):
     return cpu_ref.as_params(sd)
 
 
-LAP = [n for n in golden_names() if "_lap_" in n]
-SMX = [n for n in golden_names() if "softmax" in n]
+LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith("g5_drop")]
+SMX = [n for n in golden_names() if "softmax" in n and not n.startswith("g5_drop")]
 
 
 def test_fixture_inventory():
@@ -178,3 +178,32 @@ def test_geometry_matches_reference_modules():
         assert [(k, tuple(s)) for k, s in cfg.param_shapes()] == [(k, tuple(s)) for k, s in g["keys"]]
     assert C.ref6_laplace().receptive_field == 690      # run.sh:179 comment says 691
     assert C.bl6_laplace().receptive_field == 64
+
+
+DROP = [n for n in golden_names() if n.startswith("g5_drop")]
+
+
+@pytest.mark.parametrize("name", DROP)
+def test_dropout_masks_and_oracle_reproduce_the_reference_training_forward(name):
+    """model.train(), forward(do=True): the masks re-drawn on the host in the reference's order
+    (noise.dropout_masks) + the oracle's masked stack give the reference's own outputs."""
+    from shallow_wavenet_amd import noise as swn_noise
+    cfg, d = load_golden(name)
+    assert len(DROP) >= 4
+    P = _params(cfg, d)
+    B, Tf = d["aux"].shape[0], d["aux"].shape[2]
+    torch.manual_seed(int(d["drop_seed"]))
+    drop = swn_noise.dropout_masks(cfg, B, Tf, float(d["drop_p"]))
+    keep = 1.0 - float(d["drop_p"])
+    vals = set(np.unique(drop[0].numpy()).tolist())
+    assert vals <= {0.0, np.float32(1.0 / keep).item()}
+    assert [m is not None for m in drop[1]] == [l in swn_noise.dropped_layers(cfg) and l + 1 < cfg.L for l in range(cfg.L)]
+    if cfg.kind == "laplace":
+        raw, _ = cpu_ref.laplace_stack(cfg, P, torch.from_numpy(d["aux"]), torch.from_numpy(d["fwd_audio"]), drop=drop)
+        mu = raw.transpose(1, 2)[:, :, :cfg.seg].reshape(d["fwd_0"].shape)
+        assert np.abs(mu.numpy() - d["fwd_0"]).max() <= TOL
+    else:
+        raw, _ = cpu_ref.softmax_stack(cfg, P, torch.from_numpy(d["fwd_audio_idx"]), torch.from_numpy(d["aux"]), drop=drop)
+        lg = raw.transpose(1, 2).numpy()
+        assert np.abs(lg[:, :64] - d["fwd_logits_head"]).max() <= 2e-4
+        assert np.abs(lg[:, -64:] - d["fwd_logits_tail"]).max() <= 2e-4
