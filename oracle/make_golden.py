@@ -277,6 +277,47 @@ def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p):
     print(f"[golden] {name}: B={B} p={p} mask check err={err:.2e} loss={loss.item():.4f} {time.time() - t0:.1f}s")
 
 
+def gen_trainstep(name, cfg, n_frames, batch_size, chunk_index, wseed, data_seed, step_seed, p, n_fft_facts):
+    """one stage-4 training chunk (train_cswnv...py:700-874) through the REFERENCE's CSWNV / LaplaceLoss / LSDloss on
+    the CPU: dropout masks, reparameterised sample, NLL + complex-STFT L1, backward.  The chunk slicing and the loss
+    assembly are the restatement in shallow_wavenet_amd/train_driver.py (the reference script itself cannot be
+    imported: soundfile / h5py are absent), so this fixture pins the network + loss modules under that assembly."""
+    from shallow_wavenet_amd import train_driver as T
+    t0 = time.time()
+    m = ref_c.CSWNV(**cfg.ctor_kwargs(), do_prob=p)
+    sd = synth_state_dict(cfg, seed=wseed, flavor="trained")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.train()
+    for prm in m.parameters():
+        prm.requires_grad = True
+    for prm in m.scale_in.parameters():
+        prm.requires_grad = False
+    rng = np.random.Generator(np.random.PCG64([data_seed, 21]))
+    h = rng.standard_normal((n_frames, cfg.n_aux)).astype(np.float32)
+    x = np.tanh(0.3 * np.convolve(rng.standard_normal(n_frames * cfg.U), np.ones(8) / 8.0, mode="same")).astype(np.float32)
+    plan = T.chunk_plan(n_frames, m.receptive_field, batch_size, cfg.seg, cfg.U)
+    h_bs, x_bs, h_ss, x_ss = plan[chunk_index]
+    bh, bx, trg, xp, flen = T.slice_chunk(m, torch.from_numpy(x), torch.from_numpy(h), h_bs, x_bs, h_ss, x_ss)
+    fft = T.fft_sizes(n_fft_facts)
+    win = [torch.hann_window(n) for n in fft]
+    torch.manual_seed(step_seed)
+    loss, l_lap, l_lsd, l_err = T.batch_loss(m, ref_c.LaplaceLoss(), ref_c.LSDloss(), bh, bx, trg, xp, flen, h_ss, fft, win,
+                                             do=True)
+    loss.backward()
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, x=x, h=h, plan=np.array(plan), chunk_index=chunk_index,
+               batch_size=batch_size, step_seed=step_seed, drop_p=np.float64(p), n_fft_facts=n_fft_facts, feat_len=flen,
+               loss=np.float64(loss.item()), loss_laplace=np.float64(l_lap.item()),
+               loss_lsd=np.float64(l_lsd.item() if l_lsd is not None else np.nan), loss_err=np.float64(l_err.item()))
+    for k, prm in m.named_parameters():
+        gnp = prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+        out[f"gdig_{k}"] = digest(gnp)
+        if gnp.size <= 4096:
+            out[f"grad_{k}"] = gnp
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: plan={plan} chunk={chunk_index} feat_len={flen} loss={loss.item():.5f} "
+          f"nll={l_lap.item():.5f} err={l_err.item():.5f} {time.time() - t0:.1f}s")
+
+
 def gen_numerics():
     """G3: mu-law tables, Laplace transform grid, geometry and state-dict listings."""
     out = {}
@@ -364,6 +405,16 @@ def main():
     jobs.append(("g5_drop_tiny_softmax", gen_dropout,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[6, 5], wseed=34, flavor="xavier", aux_seed=3,
                       drop_seed=44, p=0.5)))
+    # one stage-4 training chunk: dropout + LP mean + NLL + STFT L1 through the reference modules
+    jobs.append(("g6_trainstep_tiny_s5l4", gen_trainstep,
+                 dict(cfg=C.tiny("laplace", 5, 4), n_frames=40, batch_size=300, chunk_index=1, wseed=51, data_seed=7,
+                      step_seed=61, p=0.5, n_fft_facts=5)))
+    jobs.append(("g6_trainstep_tiny_s1l0", gen_trainstep,
+                 dict(cfg=C.tiny("laplace", 1, 0), n_frames=40, batch_size=300, chunk_index=0, wseed=52, data_seed=8,
+                      step_seed=62, p=0.5, n_fft_facts=5)))
+    jobs.append(("g6_trainstep_tiny_s1l4_tail", gen_trainstep,
+                 dict(cfg=C.tiny("laplace", 1, 4), n_frames=40, batch_size=300, chunk_index=-1, wseed=53, data_seed=9,
+                      step_seed=63, p=0.25, n_fft_facts=5)))
     jobs.append(("g0_tiny_softmax", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[8, 6], wseed=13,
                       flavor="xavier", aux_seed=3, noise_seed=7, with_grads=True)))
