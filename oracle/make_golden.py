@@ -418,6 +418,9 @@ def main():
     jobs.append(("g0_tiny_softmax", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[8, 6], wseed=13,
                       flavor="xavier", aux_seed=3, noise_seed=7, with_grads=True)))
+    jobs.append(("g0_tiny_softmax_audioin", gen_softmax,
+                 dict(cfg=C.tiny("softmax", wav_conv_flag=False, audio_in_flag=True), frames=[8, 6], wseed=17,
+                      flavor="xavier", aux_seed=3, noise_seed=9, with_grads=True)))
     jobs.append(("g0_tiny_softmax_wav", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=True), frames=[8, 6], wseed=14,
                       flavor="xavier", aux_seed=3, noise_seed=8, with_grads=False)))

@@ -174,6 +174,7 @@ struct GateBwd {
     // dropout mode (appended, null = off)
     const float* gx;       // (B, L, 2H, Tp) sample-rate in_x products (no bias) of the masked conditioning
     const float* in_mul;   // (B, H, Tp) mask on this layer's INPUT h_{l-1}: it was the dropped output of layer l-1
+    float* gwxa;           // softmax audio_in: gradient of the one-hot columns of in_x, [L][Q][2H] (packed wxa section)
 };
 
 template <int KIND>
@@ -206,8 +207,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
             gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
         }
     }
+    int idx = 0;
     if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
-        int idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q; idx = idx < 0 ? idx + g.Q : idx;
+        idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q; idx = idx < 0 ? idx + g.Q : idx;
         const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
         gz += wa[o]; gc += wa[H + o];
     }
@@ -218,6 +220,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     *az = dz * gz; *ac = dc * gc;                           // da
     a.dgx[((size_t)b * H2 + o) * a.Tp + t] = dz * sz;
     a.dgx[((size_t)b * H2 + H + o) * a.Tp + t] = dc * sc;
+    if (KIND == SWN_KIND_SOFTMAX && g.audio_in && a.gwxa) {      // one-hot input column idx: d in_x.W[o][A0+idx] += dgx
+        atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + o, dz * sz);
+        atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + H + o, dc * sc);
+    }
     a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z * im;   // highway path (through the input's dropout mask)
 }
 
@@ -462,6 +468,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx;
     ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
     ga.gx = drop ? gx : nullptr;
+    ga.gwxa = g.audio_in ? gpacked + y.wxa : nullptr;
     for (int l = L - 1; l >= 0; --l) {
         ga.l = l;
         // dropout mode: this layer's input is h_{l-1} times the mask drawn for layer l-1's output (cswnv_shift1.py:269-273)

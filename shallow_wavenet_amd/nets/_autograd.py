@@ -48,8 +48,10 @@ def unfold_packed_grads(cfg: NetConfig, gp: torch.Tensor, params: Dict[str, torc
     g["upsampling.conv.bias"] = (gbx * wsum).sum().reshape(1) + sec("bup", 1)
     for l in range(L):
         gw = gwx[l].permute(1, 2, 0).reshape(H2, A0 * seg) + gbx[l][:, None] * b_up        # [o][c*seg+s]
-        if cfg.kind == "softmax" and cfg.audio_in_flag:
-            raise NotImplementedError("audio_in_flag gradients are not built")
+        if cfg.kind == "softmax" and cfg.audio_in_flag:         # one-hot columns A0 .. A0+Q-1 (dswnv.py:255-256)
+            Q = cfg.n_quantize
+            gwa = sec("wxa", L * Q * H2).view(L, Q, H2)[l].t()                              # [o][q]
+            gw = torch.cat((gw, gwa), 1)
         if c2d:
             w_in = params[f"in_x.{l}.weight"][:, :, 0]
             g["aux_conv2d.weight"] += (w_in.t() @ gw).reshape(A0, A0, seg, 1)
