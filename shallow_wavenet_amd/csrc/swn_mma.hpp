@@ -1,0 +1,31 @@
+// fp32 tile product on the matrix cores, shared by the fp32 parity / training kernels
+// (tf_layer, gemm_wx, time_gemm, reduce_gemm).
+//
+// v_mfma_f32_16x16x4_f32 multiplies fp32 operands exactly like an fmaf chain (no reduced-precision inputs), so the
+// results stay within the fp32 parity tolerances, while one instruction does 1024 MACs: the 64x64x16 tile step
+// that cost 1024 v_fma + 128 LDS reads per thread group now costs 16 MFMAs + 20 LDS reads per wave.
+//
+// Geometry: a workgroup of 4 waves owns a 64 x 64 output tile; the k-tile lives in LDS as As[16][SWN_MMA_PITCH]
+// (k-major: As[k][row]) and Bs[16][SWN_MMA_PITCH] (Bs[k][col]).  Wave w owns columns 16w..16w+15 of all 64 rows as
+// four 16x16 accumulators:   acc[mt][i] = C[16*mt + 4*(lane/16) + i][16*w + lane%16]
+// Pitch 80 floats: the four k-rows a wave reads at once (k0 + lane/16) fall into four disjoint groups of 16 banks.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define SWN_MMA_PITCH 80
+typedef float swn_f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void swn_mma_64x64x16(const float (*As)[SWN_MMA_PITCH], const float (*Bs)[SWN_MMA_PITCH],
+                                                 swn_f32x4 (&acc)[4], const int lane, const int w) {
+    const int kq = lane >> 4, rc = lane & 15;
+#pragma unroll
+    for (int k0 = 0; k0 < 16; k0 += 4) {
+        const float b = Bs[k0 + kq][16 * w + rc];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(As[k0 + kq][16 * mt + rc], b, acc[mt], 0, 0, 0);
+    }
+}
+// row / column of accumulator element (mt, i) inside the 64x64 tile
+__device__ __forceinline__ int swn_mma_row(int lane, int mt, int i) { return 16 * mt + 4 * (lane >> 4) + i; }
+__device__ __forceinline__ int swn_mma_col(int lane, int w) { return 16 * w + (lane & 15); }

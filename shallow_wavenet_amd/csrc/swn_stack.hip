@@ -12,6 +12,7 @@
 // a backward pass can reuse them.  Every product is an fp32 fma chain in ascending-k order.
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
+#include "swn_mma.hpp"
 
 namespace {
 
@@ -71,20 +72,19 @@ __global__ __launch_bounds__(256) void tf_input_kernel(const FwdArgs a) {
 // x (2 gate + 2 candidate rows); fused epilogue writes h_l.
 template <int KIND>
 __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const int l, const float* __restrict__ in_mul) {
-    __shared__ float As[16][64 + 4];      // [k][tile row]: rows 0..31 gate, 32..63 candidate
-    __shared__ float Bs[16][64 + 4];      // [k][position]
+    __shared__ float As[16][SWN_MMA_PITCH];      // [k][tile row]: rows 0..31 gate, 32..63 candidate
+    __shared__ float Bs[16][SWN_MMA_PITCH];      // [k][position]
     const SwnGeom& g = a.g;
     const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg;
     const int b = blockIdx.z;
     const int t0 = blockIdx.x * 64, o0 = blockIdx.y * 32;
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;               // tx: 4 positions, ty: 2+2 rows
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int dil = g.dil[l];
     const float* P = a.P;
     const float* hprev = a.hs + ((size_t)b * (g.L + 1) + l) * H * a.Tp;
     float* hnext = a.hs + ((size_t)b * (g.L + 1) + l + 1) * H * a.Tp;
     const float* W = P + a.y.wd + (size_t)l * H2 * K * Hp;            // [o2][k][i]
-    float acc[4][4] = {};                                               // [row: z0,z1,c0,c1][pos]
+    swn_f32x4 acc[4] = {};          // M-tiles 0,1: gate rows of channels o0..o0+31 ; 2,3: their candidate rows
     const int Kd = K * Hp;
     for (int k0 = 0; k0 < Kd; k0 += 16) {
         {   // A tile: 64 rows x 16 k, k contiguous in memory
@@ -105,49 +105,36 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
             Bs[kk][tt] = v;
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float2 az = *reinterpret_cast<const float2*>(&As[kk][2 * ty]);
-            const float2 ac = *reinterpret_cast<const float2*>(&As[kk][32 + 2 * ty]);
-            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
-            const float av[4] = {az.x, az.y, ac.x, ac.y};
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
-        }
+        swn_mma_64x64x16(As, Bs, acc, lane, w);
         __syncthreads();
     }
-    // ---- epilogue: conditioning (hoisted in_x + rank-1 upsampler), gate, highway
+    // ---- epilogue: conditioning (hoisted in_x + rank-1 upsampler), gate, highway.  A lane holds, for its position
+    //      t, the gate rows (M-tiles 0,1) and the candidate rows (M-tiles 2,3) of the same 8 channels.
+    const int t = t0 + swn_mma_col(lane, w);
+    if (t >= a.Tp) return;
     const float* condb = a.cond + (size_t)b * a.Tf * g.N;
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        const int o = o0 + 2 * ty + r;
-        if (o >= H) continue;
-        const float bz = P[a.y.bd + (size_t)l * H2 + o], bc = P[a.y.bd + (size_t)l * H2 + H + o];
-        const float bxz = P[a.y.bx + (size_t)l * H2 + o], bxc = P[a.y.bx + (size_t)l * H2 + H + o];
-        float hv[4];
+    for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t0 + 4 * tx + j;
-            hv[j] = 0.f;
-            if (t >= a.Tp) continue;
+        for (int i = 0; i < 4; ++i) {
+            const int o = o0 + swn_mma_row(lane, mt, i);
+            if (o >= H) continue;
+            const float bz = P[a.y.bd + (size_t)l * H2 + o], bc = P[a.y.bd + (size_t)l * H2 + H + o];
             float gz, gc;
             if (a.gx) {      // dropout mode: in_x evaluated at sample rate on the masked conditioning
                 const float* gr = a.gx + (((size_t)b * g.L + l) * H2) * a.Tp + t;
                 gz = gr[(size_t)o * a.Tp] + P[a.y.bxr + (size_t)l * H2 + o];
                 gc = gr[(size_t)(H + o) * a.Tp] + P[a.y.bxr + (size_t)l * H2 + H + o];
             } else {
-                gz = bxz; gc = bxc;
+                gz = P[a.y.bx + (size_t)l * H2 + o]; gc = P[a.y.bx + (size_t)l * H2 + H + o];
                 for (int s = 0; s < seg; ++s) {
                     const int tt = t + s + a.coff;
                     int f = tt / g.U; const int jj = tt - f * g.U;
                     f = f < a.Tf ? f : a.Tf - 1;
-                    const float w = P[a.y.wup + jj];
+                    const float wv = P[a.y.wup + jj];
                     const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
-                    gz = fmaf(w, cr[o], gz);
-                    gc = fmaf(w, cr[H + o], gc);
+                    gz = fmaf(wv, cr[o], gz);
+                    gc = fmaf(wv, cr[H + o], gc);
                 }
             }
             if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
@@ -156,20 +143,11 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
                 const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
                 gz += wa[o]; gc += wa[H + o];
             }
-            const float z = sigm(gz * (acc[r][j] + bz));
-            const float c = tanhf(gc * (acc[2 + r][j] + bc));
+            const float z = sigm(gz * (acc[mt][i] + bz));
+            const float c = tanhf(gc * (acc[2 + mt][i] + bc));
             const float hin = hprev[(size_t)o * a.Tp + t] * (in_mul ? in_mul[((size_t)b * H + o) * a.Tp + t] : 1.f);
-            hv[j] = (1.f - z) * c + z * hin;
+            hnext[(size_t)o * a.Tp + t] = (1.f - z) * c + z * hin;
         }
-        float* dst = hnext + (size_t)o * a.Tp + t0 + 4 * tx;
-        if (t0 + 4 * tx + 3 < a.Tp && (a.Tp & 3) == 0) {
-            *reinterpret_cast<float4*>(dst) = make_float4(hv[0], hv[1], hv[2], hv[3]);
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (t0 + 4 * tx + j < a.Tp) dst[j] = hv[j];
-        }
-    }
 }
 
 // ---- Y[b][m][t] = act(sum_k W[m][k] X[b][k][t] + bias[m]) : 64x64 tile, BK=16, 4x4 per thread -----
@@ -178,15 +156,13 @@ __global__ __launch_bounds__(256) void gemm_wx_kernel(const float* __restrict__ 
                                                       const float* __restrict__ X, size_t xstride_b,
                                                       float* __restrict__ Y, size_t ystride_b,
                                                       int M, int Kd, int T, int relu) {
-    __shared__ float As[16][64 + 4];
-    __shared__ float Bs[16][64 + 4];
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-    const int tid = threadIdx.x;
-    const int tx = tid & 15, ty = tid >> 4;
+    __shared__ float As[16][SWN_MMA_PITCH];
+    __shared__ float Bs[16][SWN_MMA_PITCH];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* Xb = X + (size_t)b * xstride_b;
     float* Yb = Y + (size_t)b * ystride_b;
-    float acc[4][4] = {};
+    swn_f32x4 acc[4] = {};
     for (int k0 = 0; k0 < Kd; k0 += 16) {
         {
             const int rr = tid >> 2, kq = (tid & 3) * 4;
@@ -204,33 +180,20 @@ __global__ __launch_bounds__(256) void gemm_wx_kernel(const float* __restrict__ 
             Bs[kk][tt] = (k0 + kk < Kd && t0 + tt < T) ? Xb[(size_t)(k0 + kk) * T + t0 + tt] : 0.f;
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float4 aa = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
-            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
-            const float av[4] = {aa.x, aa.y, aa.z, aa.w};
-            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
-        }
+        swn_mma_64x64x16(As, Bs, acc, lane, w);
         __syncthreads();
     }
+    const int t = t0 + swn_mma_col(lane, w);
+    if (t >= T) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * ty + r;
-        if (m >= M) continue;
-        const float bv = bias[m];
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t0 + 4 * tx + j;
-            if (t < T) {
-                const float v = acc[r][j] + bv;
-                Yb[(size_t)m * T + t] = relu ? fmaxf(v, 0.f) : v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + swn_mma_row(lane, mt, i);
+            if (m >= M) continue;
+            const float v = acc[mt][i] + bias[m];
+            Yb[(size_t)m * T + t] = relu ? fmaxf(v, 0.f) : v;
         }
-    }
 }
 
 size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }

@@ -13,6 +13,7 @@
 // are recomputed (one extra conv GEMM per layer) instead of being stored.
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
+#include "swn_mma.hpp"
 
 namespace {
 
@@ -30,65 +31,71 @@ struct TimeGemm {
     int XT;                                         // X is valid on [0, XT) (0: same as T)
 };
 
-// 64(m) x 64(t) tile, BK = 16 over k = (tap, c); thread = 4 x 4.
+// 64(m) x 64(t) tile, BK = 16 over k = (tap, c); product on the matrix cores (swn_mma.hpp).
 __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
-    __shared__ float As[16][64 + 4];
-    __shared__ float Bs[16][64 + 4];
+    __shared__ float As[16][SWN_MMA_PITCH];
+    __shared__ float Bs[16][SWN_MMA_PITCH];
     const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* Xb = g.X + (size_t)b * g.x_sb;
     const int Kd = g.taps * g.KC;
-    float acc[4][4] = {};
-    for (int k0 = 0; k0 < Kd; k0 += 16) {
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e & 15, mm = e >> 4;
-            const int k = k0 + kk, m = m0 + mm;
-            float v = 0.f;
-            if (k < Kd && m < g.M) { const int tap = k / g.KC, c = k - tap * g.KC; v = g.A[m * g.a_sm + tap * g.a_stap + c * g.a_sc]; }
-            As[kk][mm] = v;
+    swn_f32x4 acc[4] = {};
+    // (tap, c) of the k index each thread loads, advanced by 16 per k-tile without divisions:
+    // A tile: thread owns k-row kk = tid & 15 for rows (tid >> 4) + 16 i ; B tile: k-rows (tid >> 6) + 4 i, column tid & 63
+    const int kka = tid & 15, tt = tid & 63;
+    int tapA = kka / g.KC, cA = kka - tapA * g.KC;
+    int tapB[4], cB[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int kk = (tid >> 6) + 4 * i; tapB[i] = kk / g.KC; cB[i] = kk - tapB[i] * g.KC; }
+    const int XT = g.XT ? g.XT : g.T;
+    const bool tok = t0 + tt < g.T;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {       // global -> registers (the LDS stores follow the MFMAs of the previous tile)
+        const bool ka = k0 + kka < Kd;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (tid >> 4) + 16 * i;
+            ra[i] = (ka && m < g.M) ? g.A[m * g.a_sm + tapA * g.a_stap + cA * g.a_sc] : 0.f;
         }
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e >> 6, tt = e & 63;
-            const int k = k0 + kk;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
             float v = 0.f;
-            if (k < Kd) {
-                const int tap = k / g.KC, c = k - tap * g.KC;
-                const int ts = t0 + tt + g.sgn * (tap - g.center) * g.dil;
-                if (ts >= 0 && ts < (g.XT ? g.XT : g.T) && t0 + tt < g.T) {
-                    v = Xb[c * g.x_sc + ts * g.x_st];
-                    if (g.xmul) v *= g.xmul[(size_t)b * g.xm_sb + (size_t)c * g.xm_sc + ts];
+            if (k0 + (tid >> 6) + 4 * i < Kd) {
+                const int ts = t0 + tt + g.sgn * (tapB[i] - g.center) * g.dil;
+                if (ts >= 0 && ts < XT && tok) {
+                    v = Xb[cB[i] * g.x_sc + ts * g.x_st];
+                    if (g.xmul) v *= g.xmul[(size_t)b * g.xm_sb + (size_t)cB[i] * g.xm_sc + ts];
                 }
             }
-            Bs[kk][tt] = v;
+            rb[i] = v;
         }
+        cA += 16; while (cA >= g.KC) { cA -= g.KC; ++tapA; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { cB[i] += 16; while (cB[i] >= g.KC) { cB[i] -= g.KC; ++tapB[i]; } }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < Kd; k0 += 16) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { As[kka][(tid >> 4) + 16 * i] = ra[i]; Bs[(tid >> 6) + 4 * i][tt] = rb[i]; }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float4 aa = *reinterpret_cast<const float4*>(&As[kk][4 * ty]);
-            const float4 bb = *reinterpret_cast<const float4*>(&Bs[kk][4 * tx]);
-            const float av[4] = {aa.x, aa.y, aa.z, aa.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
-        }
+        if (k0 + 16 < Kd) fetch(k0 + 16);          // next tile's loads fly under this tile's MFMAs
+        swn_mma_64x64x16(As, Bs, acc, lane, w);
         __syncthreads();
     }
+    const int t = t0 + swn_mma_col(lane, w);
+    if (t >= g.T) return;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * ty + r;
-        if (m >= g.M) continue;
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t0 + 4 * tx + j;
-            if (t >= g.T) continue;
-            float v = acc[r][j];
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + swn_mma_row(lane, mt, i);
+            if (m >= g.M) continue;
+            float v = acc[mt][i];
             if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
             if (g.ymul) v *= g.ymul[(size_t)b * g.ym_sb + (size_t)m * g.ym_sm + t];
             float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
             *y = g.accumulate ? *y + v : v;
         }
-    }
 }
 
 struct ReduceGemm {
@@ -102,66 +109,74 @@ struct ReduceGemm {
 };
 
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
-    __shared__ float Ps[16][64 + 4];
-    __shared__ float Qs[16][64 + 4];
+    __shared__ float Ps[16][SWN_MMA_PITCH];
+    __shared__ float Qs[16][SWN_MMA_PITCH];
     const int nseg = (g.T + g.TS - 1) / g.TS;
     const int b = blockIdx.z / nseg, ts0 = (blockIdx.z - b * nseg) * g.TS;
     const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Nc = g.taps * g.KC;
     const float* Pb = g.P + (size_t)b * g.p_sb;
     const float* Qb = g.Q + (size_t)b * g.q_sb;
-    float acc[4][4] = {};
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    swn_f32x4 acc[4] = {};
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};        // partial row sums of P: thread (tid&15 = time, tid>>4 + 16 i = row)
     const int tend = ts0 + g.TS < g.T ? ts0 + g.TS : g.T;
+    // the four Q columns this thread stages: (tap, c) and the time shift, fixed for the whole time loop
+    int qc[4], qshift[4]; bool qok[4];
+    const int QT = g.QT ? g.QT : g.T;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nc = n0 + (tid >> 4) + 16 * i;
+        const int tap = nc / g.KC;
+        qok[i] = nc < Nc; qc[i] = nc - tap * g.KC; qshift[i] = g.sgn * (tap - g.center) * g.dil;
+    }
     for (int t0 = ts0; t0 < tend; t0 += 16) {
-        for (int e = tid; e < 16 * 64; e += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i;
             const int kk = e & 15, mm = e >> 4;        // time fastest: coalesced when p_st == 1
             const int t = t0 + kk, m = m0 + mm;
-            Ps[kk][mm] = (t < tend && m < g.M) ? Pb[m * g.p_sm + t * g.p_st] : 0.f;
+            const float v = (t < tend && m < g.M) ? Pb[m * g.p_sm + t * g.p_st] : 0.f;
+            Ps[kk][mm] = v;
+            rs[i] += v;
         }
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e & 15, nn = e >> 4;
-            const int t = t0 + kk, nc = n0 + nn;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int kk = tid & 15, nn = (tid >> 4) + 16 * i;
+            const int t = t0 + kk;
             float v = 0.f;
-            if (t < tend && nc < Nc) {
-                const int tap = nc / g.KC, c = nc - tap * g.KC;
-                const int tsrc = t + g.sgn * (tap - g.center) * g.dil;
-                if (tsrc >= 0 && tsrc < (g.QT ? g.QT : g.T)) {
-                    v = Qb[c * g.q_sc + tsrc * g.q_st];
-                    if (g.qmul) v *= g.qmul[(size_t)b * g.qm_sb + (size_t)c * g.qm_sc + tsrc];
+            if (t < tend && qok[i]) {
+                const int tsrc = t + qshift[i];
+                if (tsrc >= 0 && tsrc < QT) {
+                    v = Qb[qc[i] * g.q_sc + tsrc * g.q_st];
+                    if (g.qmul) v *= g.qmul[(size_t)b * g.qm_sb + (size_t)qc[i] * g.qm_sc + tsrc];
                 }
             }
             Qs[kk][nn] = v;
         }
         __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const float4 aa = *reinterpret_cast<const float4*>(&Ps[kk][4 * ty]);
-            const float4 bb = *reinterpret_cast<const float4*>(&Qs[kk][4 * tx]);
-            const float av[4] = {aa.x, aa.y, aa.z, aa.w}, bv[4] = {bb.x, bb.y, bb.z, bb.w};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                rs[r] += av[r];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[r][j] = fmaf(av[r], bv[j], acc[r][j]);
-            }
-        }
+        swn_mma_64x64x16(Ps, Qs, acc, lane, w);
         __syncthreads();
     }
+    if (g.gb && blockIdx.y == 0) {            // bias gradient: rows summed over the 16 time lanes of each group
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = m0 + 4 * ty + r;
-        if (m >= g.M) continue;
-        if (g.gb && blockIdx.y == 0 && tx == 0) atomicAdd(g.gb + m, rs[r]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int nc = n0 + 4 * tx + j;
-            if (nc >= Nc) continue;
-            const int tap = nc / g.KC, c = nc - tap * g.KC;
-            atomicAdd(g.G + m * g.g_sm + tap * g.g_stap + c * g.g_sc, acc[r][j]);
+        for (int i = 0; i < 4; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            const int m = m0 + (tid >> 4) + 16 * i;
+            if ((tid & 15) == 0 && m < g.M) atomicAdd(g.gb + m, v);
         }
     }
+    const int nc = n0 + swn_mma_col(lane, w);
+    if (nc >= Nc) return;
+    const int tap = nc / g.KC, c = nc - tap * g.KC;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + swn_mma_row(lane, mt, i);
+            if (m < g.M) atomicAdd(g.G + m * g.g_sm + tap * g.g_stap + c * g.g_sc, acc[mt][i]);
+        }
 }
 
 // ---- gate backward: recomputed pre-activations a (B,2H,T) -> da, dgx (in place over a / second buffer),
