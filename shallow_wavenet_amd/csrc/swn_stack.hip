@@ -86,25 +86,40 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
     const float* W = P + a.y.wd + (size_t)l * H2 * K * Hp;            // [o2][k][i]
     swn_f32x4 acc[4] = {};          // M-tiles 0,1: gate rows of channels o0..o0+31 ; 2,3: their candidate rows
     const int Kd = K * Hp;
+    // tile loads: division-free (tap, i) bookkeeping, fetched into registers one k-tile ahead of the MFMAs
+    const int rr = tid >> 2, kq = (tid & 3) * 4;
+    const int oa = o0 + (rr & 31);
+    const float* wrow = W + (size_t)((rr < 32) ? oa : H + oa) * Kd;
+    const int tt = tid & 63;
+    const bool tok = t0 + tt < a.Tp;
+    int tapB[4], iB[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { const int kd = (tid >> 6) + 4 * q; tapB[q] = kd / Hp; iB[q] = kd - tapB[q] * Hp; }
+    float4 ra; float rb[4];
+    auto fetch = [&](int k0) {
+        ra = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (oa < H && k0 + kq < Kd) ra = *reinterpret_cast<const float4*>(wrow + k0 + kq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            float v = 0.f;
+            if (k0 + (tid >> 6) + 4 * q < Kd && iB[q] < H && tok) {
+                const int ts = t0 + tt - (K - 1 - tapB[q]) * dil;
+                if (ts >= 0) {
+                    v = hprev[(size_t)iB[q] * a.Tp + ts];
+                    if (in_mul) v *= in_mul[((size_t)b * H + iB[q]) * a.Tp + ts];       // input = dropped output of layer l-1
+                }
+            }
+            rb[q] = v;
+            iB[q] += 16; while (iB[q] >= Hp) { iB[q] -= Hp; ++tapB[q]; }
+        }
+    };
+    fetch(0);
     for (int k0 = 0; k0 < Kd; k0 += 16) {
-        {   // A tile: 64 rows x 16 k, k contiguous in memory
-            const int rr = tid >> 2, kq = (tid & 3) * 4;
-            const int o = o0 + (rr & 31);
-            const int row = (rr < 32) ? o : H + o;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (o < H && k0 + kq < Kd) v = *reinterpret_cast<const float4*>(W + (size_t)row * Kd + k0 + kq);
-            As[kq + 0][rr] = v.x; As[kq + 1][rr] = v.y; As[kq + 2][rr] = v.z; As[kq + 3][rr] = v.w;
-        }
-        for (int e = tid; e < 16 * 64; e += 256) {   // B tile: shifted rows of h_{l-1}
-            const int kk = e >> 6, tt = e & 63;
-            const int kd = k0 + kk;
-            const int tap = kd / Hp, i = kd - tap * Hp;
-            const int ts = t0 + tt - (K - 1 - tap) * dil;
-            float v = (kd < Kd && i < H && ts >= 0 && t0 + tt < a.Tp) ? hprev[(size_t)i * a.Tp + ts] : 0.f;
-            if (in_mul && v != 0.f) v *= in_mul[((size_t)b * H + i) * a.Tp + ts];       // input = dropped output of layer l-1
-            Bs[kk][tt] = v;
-        }
+        As[kq + 0][rr] = ra.x; As[kq + 1][rr] = ra.y; As[kq + 2][rr] = ra.z; As[kq + 3][rr] = ra.w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Bs[(tid >> 6) + 4 * q][tt] = rb[q];
         __syncthreads();
+        if (k0 + 16 < Kd) fetch(k0 + 16);
         swn_mma_64x64x16(As, Bs, acc, lane, w);
         __syncthreads();
     }
