@@ -76,20 +76,39 @@ __global__ void pack_frag_kernel(const float* __restrict__ src, int ld, int rows
 }
 
 // ---- input layer: h0[b][t][o] = softsign(causal(lift(audio)))  -> bf16 time-major
+// thread = (position, group of 8 channels): one 16-byte store per lane, a wave writes 8 whole 128-byte rows
 __global__ __launch_bounds__(256) void bf16_input_kernel(const BfArgs a) {
-    const int o = threadIdx.x & 63, b = blockIdx.y;
+    const int cg = threadIdx.x & 7, b = blockIdx.y;
     const float* au = a.audio + (size_t)b * (a.Tp + a.seg - 1);
-    const float cb = a.P[a.y.cb + o];
-    const float v0 = a.P[a.y.cv + o], v1 = a.P[a.y.cv + H + o], c0 = a.P[a.y.cc + o], c1 = a.P[a.y.cc + H + o];
-#pragma unroll 4
-    for (int i = 0; i < 16; ++i) {
-        const int t = blockIdx.x * 64 + 4 * i + (threadIdx.x >> 6);
+    float cb[8], v0[8], v1[8], c0[8], c1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int o = 8 * cg + e;
+        cb[e] = a.P[a.y.cb + o];
+        v0[e] = a.P[a.y.cv + o]; v1[e] = a.P[a.y.cv + H + o];
+        c0[e] = a.P[a.y.cc + o]; c1[e] = a.P[a.y.cc + H + o];
+    }
+#pragma unroll 2
+    for (int i = 0; i < 8; ++i) {
+        const int t = blockIdx.x * 256 + 32 * i + (threadIdx.x >> 3);
         if (t >= a.Tp) break;
         const int ai = t + a.seg - 1;
-        float acc = cb;
-        if (ai - 1 >= 0) acc += fmaf(v0, au[ai - 1], c0);
-        acc += fmaf(v1, au[ai], c1);
-        a.hs[((size_t)b * a.Tp + t) * H + o] = f2bf(acc / (1.f + fabsf(acc)));
+        const float x1 = au[ai], x0 = ai - 1 >= 0 ? au[ai - 1] : 0.f;
+        const bool has0 = ai - 1 >= 0;
+        unsigned wd[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) {
+            float r[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float acc = cb[e + q];
+                if (has0) acc += fmaf(v0[e + q], x0, c0[e + q]);
+                acc += fmaf(v1[e + q], x1, c1[e + q]);
+                r[q] = acc / (1.f + fabsf(acc));
+            }
+            wd[e >> 1] = (unsigned)f2bf(r[0]) | ((unsigned)f2bf(r[1]) << 16);
+        }
+        *reinterpret_cast<uint4*>(a.hs + ((size_t)b * a.Tp + t) * H + 8 * cg) = make_uint4(wd[0], wd[1], wd[2], wd[3]);
     }
 }
 
@@ -532,23 +551,32 @@ __global__ __launch_bounds__(256, 1) void bf16_head_kernel(const BfArgs a, const
 #pragma unroll
     for (int q = 0; q < LL; ++q) rl[q] = make_rsrc(a.hs + (size_t)(1 + q) * lstride, lstride * 2);
 
-    // One workgroup per CU with the whole register file: the 48 B fragments of a 64-position tile (6 layers x
-    // 64 positions x 128 B) are fetched one tile ahead, each 16-position column refilled as soon as its MFMAs
-    // have consumed it, so the HBM stream keeps running under the LDS / barrier phases of out_1 and out_2.
-    // Loads are branch-free buffer loads: a position past the end is an out-of-range offset and reads zeros.
-    bf16x8 ring[4][KS1];
-    auto fetch_col = [&](int tix, int nt, bf16x8 (&col)[KS1]) {
+    // One workgroup per CU.  Every wave needs all 48 B fragments of a 64-position tile (its 32 skip rows times all
+    // positions), so letting each wave load them made the tile cross the L2->L1 path four times (measured: the
+    // kernel ran at the speed of its skip-GEMM loads alone, 2.4 TB/s of HBM but 9.5 TB/s of L2 traffic).  Now wave w
+    // fetches only column w (its 16 positions x 6 layers, 12 fragments, one tile AHEAD in registers) with branch-free
+    // buffer loads (a position past the end reads zeros), publishes it in LDS in fragment order, and all four
+    // waves read the whole tile from LDS: the tile leaves L2 once.  (One buffer is enough: a tile is published
+    // after the previous tile's last barrier, when nobody reads the buffer any more.)
+    extern __shared__ __attribute__((aligned(16))) unsigned char bt[];       // [4 nt][KS1][64 lanes][16 B] = 48 KB
+    bf16x8 mycol[KS1];
+    auto fetch_col = [&](int tix) {
         const int tc = tix < n_tiles ? tix : n_tiles - 1;
-        const int b = tc / tiles_per_b, t = (tc - b * tiles_per_b) * TN + 16 * nt + n;
+        const int b = tc / tiles_per_b, t = (tc - b * tiles_per_b) * TN + 16 * w + n;
         const unsigned off = (tix < n_tiles && t < a.Tp) ? (unsigned)(b * a.Tp + t) * (H * 2u) + (unsigned)(8 * g) * 2u : OOB;
 #pragma unroll
-        for (int ks = 0; ks < KS1; ++ks) col[ks] = buf_ld_bf8(rl[ks / 2], off + 64u * (ks & 1));
+        for (int ks = 0; ks < KS1; ++ks) mycol[ks] = buf_ld_bf8(rl[ks / 2], off + 64u * (ks & 1));
     };
-#pragma unroll
-    for (int nt = 0; nt < 4; ++nt) fetch_col(blockIdx.x, nt, ring[nt]);
+    fetch_col(blockIdx.x);
 
     for (int tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
         const int b = tix / tiles_per_b, t0 = (tix - b * tiles_per_b) * TN;
+        unsigned char* btc = bt;
+#pragma unroll
+        for (int ks = 0; ks < KS1; ++ks)
+            *reinterpret_cast<bf16x8*>(btc + ((w * KS1 + ks) * 64 + lane) * 16) = mycol[ks];
+        fetch_col(tix + gridDim.x);                     // next tile's column flies under this tile's three GEMMs
+        __syncthreads();
         // ---- skip = Wsk . [h_1 .. h_L]
         f32x4 acc[2][4];
 #pragma unroll
@@ -557,10 +585,10 @@ __global__ __launch_bounds__(256, 1) void bf16_head_kernel(const BfArgs a, const
             acc[1][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < KS1; ++ks) {
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[0][ks], ring[nt][ks], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[1][ks], ring[nt][ks], acc[1][nt], 0, 0, 0);
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(btc + ((nt * KS1 + ks) * 64 + lane) * 16);
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[0][ks], bf, acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[1][ks], bf, acc[1][nt], 0, 0, 0);
             }
-            fetch_col(tix + gridDim.x, nt, ring[nt]);
         }
 #pragma unroll
         for (int m = 0; m < 2; ++m)
@@ -689,7 +717,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     a.off_wd = o.wd; a.off_wsk = o.wsk; a.off_w1 = o.w1; a.off_w2 = o.w2;
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(bf16_input_kernel, dim3((unsigned)((Tp + 63) / 64), batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(bf16_input_kernel, dim3((unsigned)((Tp + 255) / 256), batch), dim3(256), 0, st, a);
     const int n_tiles = batch * (int)((Tp + TN - 1) / TN);
     const int n_chunks = batch * (int)((Tp + 15) / 16);
     const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
@@ -708,6 +736,6 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
             hipLaunchKernelGGL(bf16_layer_kernel<false>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
     }
     const int hgrid = n_tiles < 256 ? n_tiles : 256;
-    hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 0, st, a, n_tiles);
+    hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 4 * 12 * 64 * 16, st, a, n_tiles);
     return swn_launch_status("swn_forward_bf16");
 }
