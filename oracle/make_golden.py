@@ -318,6 +318,44 @@ def gen_trainstep(name, cfg, n_frames, batch_size, chunk_index, wseed, data_seed
           f"nll={l_lap.item():.5f} err={l_err.item():.5f} {time.time() - t0:.1f}s")
 
 
+def gen_trainstep_softmax(name, cfg, n_frames, batch_size, chunk_index, wseed, data_seed, step_seed, p):
+    """one stage-7 training chunk (train_dswnv_softmax.py:549-575) through the REFERENCE's DSWNV on the CPU (one-hot
+    input, dropout, cross entropy past the receptive field, backward); chunk slicing / loss assembly from
+    shallow_wavenet_amd/train_softmax_driver.py."""
+    from shallow_wavenet_amd import train_softmax_driver as S
+    t0 = time.time()
+    m = ref_d.DSWNV(**cfg.ctor_kwargs(), do_prob=p)
+    sd = synth_state_dict(cfg, seed=wseed, flavor="xavier")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.train()
+    for prm in m.scale_in.parameters():
+        prm.requires_grad = False
+    rng = np.random.Generator(np.random.PCG64([data_seed, 22]))
+    h = rng.standard_normal((n_frames, cfg.n_aux)).astype(np.float32)
+    xc = rng.integers(0, cfg.n_quantize, size=n_frames * cfg.U).astype(np.int64)
+    plan = S.chunk_plan(n_frames, m.receptive_field, batch_size, cfg.U)
+    h_bs, x_bs, h_ss, x_ss = plan[chunk_index]
+    bh, bx, trg = S.slice_chunk(torch.from_numpy(xc), torch.from_numpy(h), h_bs, x_bs, h_ss, x_ss)
+
+    class OneHotInput:          # the reference takes the one-hot tensor the script builds with OneHot (:123-131)
+        receptive_field = m.receptive_field
+        def __call__(self, idx, aux, do=False):
+            return m(ref_d.OneHot(idx, cfg.n_quantize).transpose(1, 2), aux, do=do)
+
+    torch.manual_seed(step_seed)
+    loss = S.batch_loss(OneHotInput(), torch.nn.CrossEntropyLoss(), bh, bx, trg, h_ss, do=True)
+    loss.backward()
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, xc=xc, h=h, plan=np.array(plan), chunk_index=chunk_index,
+               batch_size=batch_size, step_seed=step_seed, drop_p=np.float64(p), loss=np.float64(loss.item()))
+    for k, prm in m.named_parameters():
+        gnp = prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+        out[f"gdig_{k}"] = digest(gnp)
+        if gnp.size <= 4096:
+            out[f"grad_{k}"] = gnp
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: plan={plan} chunk={chunk_index} loss={loss.item():.5f} {time.time() - t0:.1f}s")
+
+
 def gen_numerics():
     """G3: mu-law tables, Laplace transform grid, geometry and state-dict listings."""
     out = {}
@@ -415,6 +453,9 @@ def main():
     jobs.append(("g6_trainstep_tiny_s1l4_tail", gen_trainstep,
                  dict(cfg=C.tiny("laplace", 1, 4), n_frames=40, batch_size=300, chunk_index=-1, wseed=53, data_seed=9,
                       step_seed=63, p=0.25, n_fft_facts=5)))
+    jobs.append(("g6_trainstep_tiny_softmax", gen_trainstep_softmax,
+                 dict(cfg=C.tiny("softmax", wav_conv_flag=False), n_frames=40, batch_size=300, chunk_index=1, wseed=54,
+                      data_seed=10, step_seed=64, p=0.5)))
     jobs.append(("g0_tiny_softmax", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[8, 6], wseed=13,
                       flavor="xavier", aux_seed=3, noise_seed=7, with_grads=True)))

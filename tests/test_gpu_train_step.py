@@ -17,7 +17,7 @@ from test_gpu_backward_parity import _check
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("g6_trainstep")])
+@pytest.mark.parametrize("name", [n for n in golden_names() if n.startswith("g6_trainstep") and "softmax" not in n])
 def test_training_chunk_matches_reference_modules(gpu_ok, name):
     cfg, d = load_golden(name)
     m = mc.CSWNV(**cfg.ctor_kwargs(), do_prob=float(d["drop_p"]))
@@ -50,3 +50,31 @@ def test_training_chunk_matches_reference_modules(gpu_ok, name):
     opt.step()
     moved = [k for k, v in m.state_dict().items() if not torch.equal(v, before[k])]
     assert "scale_in.weight" not in moved and "out_2.weight" in moved and "conv_aux.conv.0.weight" in moved
+
+
+def test_softmax_training_chunk_matches_reference_module(gpu_ok):
+    """stage 7 (train_dswnv_softmax.py:549-575): mu-law classes in, dropout, cross entropy past the receptive field."""
+    from shallow_wavenet_amd import train_softmax_driver as S
+    from shallow_wavenet_amd.nets import dswnv as md
+    name = "g6_trainstep_tiny_softmax"
+    cfg, d = load_golden(name)
+    m = md.DSWNV(**cfg.ctor_kwargs(), do_prob=float(d["drop_p"]))
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=int(d["wseed"]), flavor="xavier").items()})
+    m.cuda().train()
+    for p in m.scale_in.parameters():
+        p.requires_grad = False
+    plan = [tuple(int(v) for v in r) for r in d["plan"]]
+    assert plan == S.chunk_plan(d["h"].shape[0], m.receptive_field, int(d["batch_size"]), cfg.U)
+    h_bs, x_bs, h_ss, x_ss = plan[int(d["chunk_index"])]
+    bh, bx, trg = S.slice_chunk(torch.from_numpy(d["xc"]).cuda(), torch.from_numpy(d["h"]).cuda(), h_bs, x_bs, h_ss, x_ss)
+    torch.manual_seed(int(d["step_seed"]))
+    loss = S.batch_loss(m, torch.nn.CrossEntropyLoss(), bh, bx, trg, h_ss, do=True)
+    assert abs(loss.item() - float(d["loss"])) <= 2e-5 * max(1.0, abs(float(d["loss"])))
+    opt = torch.optim.Adam(S.optimizer_parameters(m), lr=1e-4)
+    opt.zero_grad()
+    loss.backward()
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    _check(name, m, d)
+    opt.step()

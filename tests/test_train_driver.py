@@ -11,7 +11,7 @@ from shallow_wavenet_amd.nets import cswnv_shift1 as mc
 
 
 def test_chunk_plan_matches_fixture_and_tiles_the_utterance():
-    for name in [n for n in golden_names() if n.startswith("g6_trainstep")]:
+    for name in [n for n in golden_names() if n.startswith("g6_trainstep") and "softmax" not in n]:
         cfg, d = load_golden(name)
         plan = T.chunk_plan(d["h"].shape[0], cfg.receptive_field, int(d["batch_size"]), cfg.seg, cfg.U)
         assert np.array_equal(np.array(plan), d["plan"])
@@ -84,3 +84,22 @@ def test_cli_flags_are_the_reference_flags():
     assert want <= have
     ns = T.build_parser().parse_args(["--expdir", "x", "--aux_conv2d_flag", "true", "--wav_conv_flag", "false"])
     assert ns.aux_conv2d_flag is True and ns.wav_conv_flag is False and ns.lr == 1e-4 and ns.batch_size == 8800
+
+
+def test_softmax_driver_chunk_plan_and_flags():
+    from shallow_wavenet_amd import train_softmax_driver as S
+    # train_dswnv_softmax.py:96-146 with the recipe's defaults (rf of the 3x3, K=6 stack = 520+..., batch 1100, U=110)
+    rf, bs, U = 265, 1100, 110
+    plan = S.chunk_plan(60, rf, bs, U)
+    eff = bs - (rf + bs + 1) % U
+    h_bs = (rf + eff + 1) // U
+    assert plan[0] == (h_bs, h_bs * U, 0, 0) and plan[-1][:2] == (-1, -1)
+    assert all(p[2] == i * (eff // U) for i, p in enumerate(plan))
+    assert S.chunk_plan(2, rf, bs, U) == []                     # 220 samples <= rf + 1: nothing to train on
+    have = {a.dest for a in S.build_parser()._actions}
+    assert {"n_quantize", "audio_in", "wav_conv_flag", "do_prob", "batch_size", "epoch_count", "stats", "resume"} <= have
+    x = torch.arange(700)
+    h = torch.zeros(40, 3)
+    bh, bx, trg = S.slice_chunk(x, h, 17, 340, 14, 280)
+    assert bh.shape == (1, 3, 17) and bx.shape == (1, 339) and trg.shape == (339,)
+    assert int(bx[0, 0]) == 280 and int(trg[0]) == 281 and int(trg[-1]) == 280 + 339
