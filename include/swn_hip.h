@@ -111,7 +111,9 @@ int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float*
  *   out_dev     laplace: (B, n_steps*seg) fp32 ; softmax: (B, n_steps) int32
  *   heads_dev   optional (B, n_steps, n_out) raw out_2 outputs at each step (may be NULL)
  *   variant     0 = auto, 1 = generic persistent kernel, 2 = register/LDS-resident BL6-class kernel,
- *               3 = stepped multi-launch decode for large geometries (REF6)                   */
+ *               3 = stepped multi-launch decode for large geometries (REF6),
+ *               4 = cohort decode of large geometries: up to 64 utterances in lock step, lanes = utterances
+ *                   (explicit only; auto keeps the stepped decode)                                            */
 size_t swn_decode_state_floats(const swn_net_desc* d, int batch);
 int    swn_decode(const swn_net_desc* d, const float* packed_dev, const float* cond_dev,
                   int batch, int n_frames, int n_steps, const float* noise_dev,

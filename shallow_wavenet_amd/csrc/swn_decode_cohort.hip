@@ -1,0 +1,420 @@
+// Cohort decode: many utterances of a LARGE geometry (REF6: H=192/256, K=7) generated in lock step,
+// LANES = UTTERANCES.
+//
+// The stepped decode (swn_decode_stepped.hip) gives every utterance its own workgroups, so B utterances read
+// the 15-24 MB of weights B times per generated sample from the Infinity Cache (B=64: ~6 TB/s of it, 162 us per
+// step).  Here the state of up to 64 utterances is stored structure-of-arrays with the utterance index fastest
+//     state[(cohort * stride + element) * 64 + lane]
+// and a wave owns one output row (pair) for all 64 utterances of a cohort: the weight of an input is ONE scalar
+// (wave-uniform) operand multiplied into 64 different activations loaded with one coalesced 256-byte load.  The
+// weights cross the chip once per step and cohort, there are no cross-lane reductions at all, and the gate /
+// sampling epilogues are plain per-lane code.  A workgroup owns a few output rows; its 16 waves split the inputs
+// (each activation load feeds all the workgroup's rows) and the partial sums meet in LDS.
+// Launch chain per step (stream order = the dependency chain, as in the stepped decode):
+//     co_in | L x co_layer | co_rowvec x 3 (skip, out_1, out_2) | co_tail            = L + 5 launches
+// Math, ring layout and sampling are those of the stepped / generic kernels (cswnv_shift1.py:348-402,
+// dswnv.py:338-374); only the order of the fp32 sums over the inputs differs (16 contiguous slices).
+#include <hip/hip_runtime.h>
+#include "swn_geom.hpp"
+#include <type_traits>
+
+namespace {
+
+constexpr int CO = 64;          // utterances per cohort = lanes of a wave
+typedef float cf4 __attribute__((ext_vector_type(4)));
+
+struct CoArgs {
+    SwnGeom g;
+    SwnLayout y;
+    const float* P; const float* cond; const float* noise; const void* forced;
+    float* state; void* out; float* heads;
+    int B, Tf, n_steps, n_pro, WN;
+    int ring_off[SWN_MAXL], ring_len[SWN_MAXL];
+    int o_hcat, o_skip, o_o1, o_o2, o_hist, stride;             // element offsets inside a cohort
+};
+
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
+__device__ __forceinline__ int pmod(int r, int m) { int t = r % m; return t < 0 ? t + m : t; }
+
+struct Iter { bool gen; int i, np, q0; };
+__device__ __forceinline__ Iter iter_of(const CoArgs& a, int it) {
+    Iter r; r.gen = it >= a.n_pro; r.i = it - a.n_pro; r.np = r.gen ? a.g.seg : 1;
+    r.q0 = r.gen ? a.g.rf + 1 - a.g.seg + r.i * a.g.seg : it;
+    return r;
+}
+
+// ---- input layer: one wave per channel, lane = utterance ----------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void co_in_kernel(const CoArgs a, const int it) {
+    const SwnGeom& g = a.g;
+    const int lane = threadIdx.x & 63, c = blockIdx.y;
+    const int o = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (o >= g.H) return;
+    const bool live = c * CO + lane < a.B;
+    float* st = a.state + (size_t)c * a.stride * CO + lane;
+    const float* P = a.P;
+    const Iter r = iter_of(a, it);
+    const int H = g.H, K = g.K, seg = g.seg, WN = a.WN;
+    for (int j = 0; j < r.np; ++j) {
+        const int q = r.q0 + j;
+        float acc = P[a.y.cb + o];
+        for (int k = 0; k < K; ++k) {
+            const int rr = q - (K - 1 - k);
+            if (KIND == SWN_KIND_LAPLACE) {
+                if (rr >= -(seg - 1)) {
+                    const int qe = r.gen ? g.rf + r.i * seg : g.rf;
+                    const float sv = r.gen ? st[(size_t)(a.o_hist + rr - qe + WN - 1) * CO] : 0.f;
+                    acc += fmaf(P[a.y.cv + (size_t)k * H + o], sv, P[a.y.cc + (size_t)k * H + o]);
+                }
+            } else if (rr >= 0) {
+                const int qe = r.gen ? g.rf + r.i : g.rf;
+                const int idx = r.gen ? __builtin_bit_cast(int, st[(size_t)(a.o_hist + rr - qe + WN - 1) * CO]) : g.Q / 2;
+                acc += P[a.y.ct + ((size_t)k * g.Q + idx) * H + o];
+            }
+        }
+        if (live) st[(size_t)(a.ring_off[0] + pmod(q, a.ring_len[0]) * g.Hp + o) * CO] = acc / (1.f + fabsf(acc));
+    }
+}
+
+// ---- one gated layer.  Workgroup = PW channel pairs (gate row o, candidate row H+o), 16 waves; wave s owns the
+//      input-channel slice [s*Hp/16, (s+1)*Hp/16) of every tap for ALL PW pairs: an activation (one coalesced
+//      256-byte load for the 64 utterances) feeds 2*PW FMAs whose weights are wave-uniform scalars, so neither
+//      the activations (re-read once per workgroup) nor the weights (once per cohort) are streamed redundantly.
+constexpr int PW = 4;           // channel pairs per workgroup
+constexpr int KS = 16;          // input slices = waves per workgroup
+
+// stage `rows` weight rows (each `len` floats, global row stride `ld`) into LDS as wsh[row][len], all threads
+__device__ __forceinline__ void stage_rows(float* wsh, const float* src, const int* rowidx, int rows, int len, int ld) {
+    const int n4 = len >> 2;
+    for (int e = threadIdx.x; e < rows * n4; e += blockDim.x) {
+        const int r = e / n4, k4 = e - r * n4;
+        *reinterpret_cast<float4*>(wsh + (size_t)r * len + 4 * k4) =
+            *reinterpret_cast<const float4*>(src + (size_t)rowidx[r] * ld + 4 * k4);
+    }
+}
+
+// The kernels are latency chains if written naively (a memory round trip per group of inputs), so each one issues
+// ALL its loads up front: the workgroup's weight rows go to LDS with one cooperative copy, every wave fetches the
+// activations of its whole input slice into registers, and only then the FMAs run (weights read back from LDS as
+// broadcasts).  Two memory latencies per launch instead of ~28.
+template <int KIND, int IPWC, int TP>      // IPWC: inputs per slice and tap, TP: taps whose activations are in flight at once
+__global__ __launch_bounds__(1024) void co_layer_kernel(const CoArgs a, const int l, const int it) {
+    extern __shared__ __attribute__((aligned(16))) float lsh[];     // weights [2*PW][K*Hp], later the partial sums
+    __shared__ int rowidx[2 * PW];
+    const SwnGeom& g = a.g;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int o0 = blockIdx.x * PW, c = blockIdx.y;
+    const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg, KH = K * Hp;
+    const int b = c * CO + lane;
+    const bool live = b < a.B;
+    float* st = a.state + (size_t)c * a.stride * CO + lane;
+    const float* P = a.P;
+    const int i0 = w * IPWC;
+    const int dil = g.dil[l], R = a.ring_len[l];
+    const Iter r = iter_of(a, it);
+    if (threadIdx.x < 2 * PW) {
+        const int u = threadIdx.x, oo = o0 + (u & (PW - 1));
+        rowidx[u] = oo < H ? (u < PW ? 0 : H) + oo : 0;
+    }
+    __syncthreads();
+    stage_rows(lsh, P + a.y.wd + (size_t)l * H2 * KH, rowidx, 2 * PW, KH, KH);
+    for (int j = 0; j < r.np; ++j) {
+        const int q = r.q0 + j;
+        // epilogue operands of the finishing waves first: their (gathered) loads fly under everything else
+        const int o = o0 + (w < PW ? w : 0);
+        const bool fin = w < PW && o < H;
+        float gz = 0.f, gc = 0.f, hp = 0.f;
+        if (fin) {
+            gz = P[a.y.bx + (size_t)l * H2 + o]; gc = P[a.y.bx + (size_t)l * H2 + H + o];
+            hp = st[(size_t)(a.ring_off[l] + pmod(q, R) * Hp + o) * CO];
+            if (live) {
+                const float* condb = a.cond + (size_t)b * a.Tf * g.N;
+                for (int s = 0; s < seg; ++s) {
+                    int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
+                    int f = tt / g.U; const int jj = tt - f * g.U;
+                    f = f < a.Tf ? f : a.Tf - 1;
+                    const float wu = P[a.y.wup + jj];
+                    const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+                    gz = fmaf(wu, cr[o], gz); gc = fmaf(wu, cr[H + o], gc);
+                }
+                if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
+                    const int qe = r.gen ? g.rf + r.i : g.rf;
+                    const int idx = r.gen ? __builtin_bit_cast(int, st[(size_t)(a.o_hist + q - qe + a.WN - 1) * CO]) : g.Q / 2;
+                    const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
+                    gz += wa[o]; gc += wa[H + o];
+                }
+            }
+        }
+        float acc[2 * PW];
+#pragma unroll
+        for (int u = 0; u < 2 * PW; ++u) acc[u] = 0.f;
+        for (int t0 = 0; t0 < K; t0 += TP) {
+            float x[TP][IPWC];
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+                const int tap = t0 + tt;
+                const float* xr = st + (size_t)(a.ring_off[l] + pmod(q - (K - 1 - (tap < K ? tap : 0)) * dil, R) * Hp + i0) * CO;
+#pragma unroll
+                for (int e = 0; e < IPWC; ++e) x[tt][e] = (tap < K && i0 + e < Hp) ? xr[(size_t)e * CO] : 0.f;
+            }
+            if (t0 == 0 && j == 0) __syncthreads();              // the staged weights are in LDS
+#pragma unroll
+            for (int tt = 0; tt < TP; ++tt) {
+                const int tap = t0 + tt;
+                if (tap < K && i0 < Hp) {
+#pragma unroll
+                    for (int e = 0; e < IPWC; e += 4)
+#pragma unroll
+                        for (int u = 0; u < 2 * PW; ++u) {
+                            const float4 wv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lsh + (size_t)u * KH + tap * Hp + ((i0 + e < Hp) ? i0 + e : 0), 16));
+                            acc[u] = fmaf(wv.x, x[tt][e], acc[u]); acc[u] = fmaf(wv.y, x[tt][e + 1], acc[u]);
+                            acc[u] = fmaf(wv.z, x[tt][e + 2], acc[u]); acc[u] = fmaf(wv.w, x[tt][e + 3], acc[u]);
+                        }
+                }
+            }
+        }
+        // partial sums live behind the weights (which later positions still need)
+        float* part = lsh + (size_t)2 * PW * KH;
+#pragma unroll
+        for (int u = 0; u < 2 * PW; ++u) part[((size_t)w * 2 * PW + u) * CO + lane] = acc[u];
+        __syncthreads();
+        if (fin) {
+            float sz = 0.f, sc = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < KS; ++s2) { sz += part[((size_t)s2 * 2 * PW + w) * CO + lane]; sc += part[((size_t)s2 * 2 * PW + PW + w) * CO + lane]; }
+            const float z = sigm(gz * (sz + P[a.y.bd + (size_t)l * H2 + o]));
+            const float cd = tanhf(gc * (sc + P[a.y.bd + (size_t)l * H2 + H + o]));
+            const float hn = (1.f - z) * cd + z * hp;
+            if (l + 1 < g.L) st[(size_t)(a.ring_off[l + 1] + pmod(q, a.ring_len[l + 1]) * Hp + o) * CO] = hn;
+            if (j == r.np - 1) st[(size_t)(a.o_hcat + l * Hp + o) * CO] = hn;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- y[row][b] = act(bias[row] + W[row][:] . x[:][b]): workgroup = RW rows, 16 waves split the inputs; same
+//      all-loads-first structure (weights to LDS, the wave's activations to registers)
+constexpr int RW = 8;
+constexpr int RV_X = 10;        // activations per wave held in registers per pass (80 inputs per pass and wave)
+
+__global__ __launch_bounds__(1024) void co_rowvec_kernel(const CoArgs a, size_t w_off, int ldw, size_t b_off, int rows, int ni,
+                                                         int x_off, int y_off, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float lsh[];     // weights [RW][ni] | partial sums [KS][RW][CO]
+    __shared__ int rowidx[RW];
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = blockIdx.x * RW, c = blockIdx.y;
+    float* st = a.state + (size_t)c * a.stride * CO + lane;
+    if (threadIdx.x < RW) rowidx[threadIdx.x] = r0 + (int)threadIdx.x < rows ? r0 + (int)threadIdx.x : 0;
+    __syncthreads();
+    stage_rows(lsh, a.P + w_off, rowidx, RW, ni, ldw);
+    const int ipw = ((ni + KS - 1) / KS + 3) & ~3, i0 = w * ipw, i1 = (i0 + ipw < ni) ? i0 + ipw : ni;
+    const float* xr = st + (size_t)x_off * CO;
+    float acc[RW];
+#pragma unroll
+    for (int u = 0; u < RW; ++u) acc[u] = 0.f;
+    bool first = true;
+    for (int ib = i0; ib < i1 || first; ib += 4 * RV_X) {
+        float x[4 * RV_X];
+#pragma unroll
+        for (int e = 0; e < 4 * RV_X; ++e) x[e] = (ib + e < i1) ? xr[(size_t)(ib + e) * CO] : 0.f;
+        if (first) { __syncthreads(); first = false; }
+#pragma unroll
+        for (int e = 0; e < 4 * RV_X; e += 4) {
+            if (ib + e < i1) {
+#pragma unroll
+                for (int u = 0; u < RW; ++u) {
+                    const float4 wv = *reinterpret_cast<const float4*>(__builtin_assume_aligned(lsh + (size_t)u * ni + ib + e, 16));
+                    acc[u] = fmaf(wv.x, x[e], acc[u]); acc[u] = fmaf(wv.y, x[e + 1], acc[u]);
+                    acc[u] = fmaf(wv.z, x[e + 2], acc[u]); acc[u] = fmaf(wv.w, x[e + 3], acc[u]);
+                }
+            }
+        }
+    }
+    float* part = lsh + (size_t)RW * ni;
+#pragma unroll
+    for (int u = 0; u < RW; ++u) part[((size_t)w * RW + u) * CO + lane] = acc[u];
+    __syncthreads();
+    if (w < RW && r0 + w < rows) {
+        float v = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < KS; ++s2) v += part[((size_t)s2 * RW + w) * CO + lane];
+        v += a.P[b_off + r0 + w];
+        st[(size_t)(y_off + r0 + w) * CO] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// ---- sampling + history update, lane = utterance.  Laplace: one wave; softmax: 4 waves split the classes ------
+template <int KIND>
+__global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int it) {
+    __shared__ float redf[4][CO];
+    __shared__ int redi[4][CO];
+    const SwnGeom& g = a.g;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c = blockIdx.x;
+    const int b = c * CO + lane;
+    const bool live = b < a.B;
+    float* st = a.state + (size_t)c * a.stride * CO + lane;
+    const float* o2 = st + (size_t)a.o_o2 * CO;
+    float* shist = st + (size_t)a.o_hist * CO;
+    const int i = it - a.n_pro, seg = g.seg, WN = a.WN;
+    if (a.heads && live && w == 0)
+        for (int e = 0; e < g.NO; ++e) a.heads[((size_t)b * a.n_steps + i) * g.NO + e] = o2[(size_t)e * CO];
+    if (KIND == SWN_KIND_LAPLACE) {
+        if (w != 0 || !live) return;
+        {
+#pragma clang fp contract(off)
+        // Laplace head, cswnv_shift1.py:368-391
+        const float* nz = a.noise + ((size_t)b * a.n_steps + i) * seg;
+        const float* forced = reinterpret_cast<const float*>(a.forced);
+        float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * seg + (size_t)i * seg;
+        float lp[16], fed[16];
+        const int lpc = g.lpc;
+        for (int k = 0; k < lpc; ++k) lp[k] = shist[(size_t)(WN - lpc + k) * CO];
+        for (int j = 0; j < seg; ++j) {
+            const float mu = o2[(size_t)j * CO], yv = o2[(size_t)(seg + j) * CO];
+            const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
+            float lpv = 0.f;
+            for (int k = 0; k < lpc; ++k) lpv += o2[(size_t)(2 * seg + lpc - 1 - k) * CO] * lp[k];
+            const float e = nz[j];
+            const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+            const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
+            float sv = (lpc > 0) ? (lpv + mu) - t : mu - t;
+            sv = fminf(fmaxf(sv, -1.f), 1.f);
+            outp[j] = sv;
+            const float fd = forced ? forced[(size_t)b * a.n_steps * seg + (size_t)i * seg + j] : sv;
+            fed[j] = fd;
+            for (int k = 0; k + 1 < lpc; ++k) lp[k] = lp[k + 1];
+            if (lpc > 0) lp[lpc - 1] = fd;
+        }
+        for (int k = 0; k + seg < WN; ++k) shist[(size_t)k * CO] = shist[(size_t)(k + seg) * CO];
+        for (int j = 0; j < seg; ++j) shist[(size_t)(WN - seg + j) * CO] = fed[j];
+        }
+    } else {
+        // softmax head, dswnv.py:361-369: p = softmax(logits); p /= sum(p); index = argmax(p / q), q ~ Exp(1)
+        const int Q = g.Q, e0 = w * ((Q + 3) / 4), e1 = (e0 + (Q + 3) / 4 < Q) ? e0 + (Q + 3) / 4 : Q;
+        const float* qn = a.noise + ((size_t)(live ? b : 0) * a.n_steps + i) * Q;
+        float m = -INFINITY;
+        for (int e = e0; e < e1; ++e) m = fmaxf(m, o2[(size_t)e * CO]);
+        redf[w][lane] = m; __syncthreads();
+        m = fmaxf(fmaxf(redf[0][lane], redf[1][lane]), fmaxf(redf[2][lane], redf[3][lane])); __syncthreads();
+        float sum = 0.f;
+        for (int e = e0; e < e1; ++e) sum += expf(o2[(size_t)e * CO] - m);
+        redf[w][lane] = sum; __syncthreads();
+        sum = (redf[0][lane] + redf[1][lane]) + (redf[2][lane] + redf[3][lane]); __syncthreads();
+        float sum2 = 0.f;
+        for (int e = e0; e < e1; ++e) sum2 += expf(o2[(size_t)e * CO] - m) / sum;
+        redf[w][lane] = sum2; __syncthreads();
+        sum2 = (redf[0][lane] + redf[1][lane]) + (redf[2][lane] + redf[3][lane]); __syncthreads();
+        float best = -1.f; int bi = 0x7fffffff;
+        for (int e = e0; e < e1; ++e) {
+            const float rr = ((expf(o2[(size_t)e * CO] - m) / sum) / sum2) / qn[e];
+            if (rr > best) { best = rr; bi = e; }
+        }
+        redf[w][lane] = best; redi[w][lane] = bi; __syncthreads();
+        if (w == 0 && live) {
+            for (int u = 1; u < 4; ++u) {          // ascending class ranges: a tie keeps the lower index
+                const float ob = redf[u][lane]; const int oi = redi[u][lane];
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            const int* forced = reinterpret_cast<const int*>(a.forced);
+            reinterpret_cast<int*>(a.out)[(size_t)b * a.n_steps + i] = bi;
+            const int fd = forced ? forced[(size_t)b * a.n_steps + i] : bi;
+            for (int k = 0; k + 1 < WN; ++k) shist[(size_t)k * CO] = shist[(size_t)(k + 1) * CO];
+            shist[(size_t)(WN - 1) * CO] = __builtin_bit_cast(float, fd);
+        }
+    }
+}
+
+// softmax: the sample window starts as the mu-law zero class
+__global__ void co_seed_kernel(const CoArgs a) {
+    const int c = blockIdx.x, lane = threadIdx.x;
+    float* st = a.state + (size_t)c * a.stride * CO + lane;
+    for (int k = 0; k < a.WN; ++k) st[(size_t)(a.o_hist + k) * CO] = __builtin_bit_cast(float, a.g.Q / 2);
+}
+
+int plan(CoArgs& a) {
+    const SwnGeom& g = a.g;
+    int o = 0;
+    for (int l = 0; l < g.L; ++l) { a.ring_off[l] = o; a.ring_len[l] = g.pad[l] + g.seg; o += a.ring_len[l] * g.Hp; }
+    a.WN = (g.K - 1 > g.lpc ? g.K - 1 : g.lpc) + g.seg;
+    a.o_hcat = o; o += g.L * g.Hp;
+    a.o_skip = o; o += g.Sp;
+    a.o_o1 = o; o += g.O1p;
+    a.o_o2 = o; o += swn_round4(g.NO);
+    a.o_hist = o; o += swn_round4(a.WN);
+    a.stride = (o + 63) & ~63;
+    return a.stride;
+}
+
+}  // namespace
+
+extern "C" size_t swn_decode_cohort_state_floats(const swn_net_desc* d, int batch) {
+    CoArgs a;
+    if (swn_make_geom(d, &a.g) < 0 || batch < 1) return 0;
+    return (size_t)plan(a) * CO * ((batch + CO - 1) / CO);
+}
+
+extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
+                                 int n_steps, const float* noise, const void* forced, float* state, void* out,
+                                 float* heads, void* stream_) {
+    CoArgs a;
+    int rc = swn_make_geom(d, &a.g);
+    if (rc < 0) return rc;
+    const SwnGeom& g = a.g;
+    if (g.seg > 16 || g.lpc > 16 || g.Hp != g.H) return SWN_E_UNSUPPORTED;
+    if (!state) return SWN_E_BADARG;
+    swn_make_layout(&a.g, &a.y);
+    plan(a);
+    a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state; a.out = out; a.heads = heads;
+    a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.n_pro = g.rf - g.seg + 1;
+    hipStream_t st = (hipStream_t)stream_;
+    const unsigned nco = (unsigned)((batch + CO - 1) / CO);
+    if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.stride * CO * nco, st) != hipSuccess) return SWN_E_LAUNCH;
+    const bool lap = g.kind == SWN_KIND_LAPLACE;
+    if (!lap) hipLaunchKernelGGL(co_seed_kernel, dim3(nco), dim3(CO), 0, st, a);
+    // slice width per wave and tap (multiple of 4); the instantiated widths cover Hp <= 256 and K <= 8
+    const int ipw = ((g.Hp + KS - 1) / KS + 3) & ~3;
+    if ((ipw != 4 && ipw != 12 && ipw != 16) || g.K > 8) return SWN_E_UNSUPPORTED;
+    const size_t lds_layer = ((size_t)2 * PW * g.K * g.Hp + (size_t)KS * 2 * PW * CO) * sizeof(float);
+    auto lds_rv = [&](int ni) { return ((size_t)RW * ni + (size_t)KS * RW * CO) * sizeof(float); };
+    const size_t lds_max = 150 * 1024;             // gfx950: 160 KB of LDS per CU, one 1024-thread workgroup each
+    if (lds_layer > lds_max || lds_rv(g.L * g.Hp) > lds_max || lds_rv(g.Sp) > lds_max || lds_rv(g.O1p) > lds_max)
+        return SWN_E_UNSUPPORTED;
+    {   // more than the default 64 KB of dynamic LDS has to be enabled per kernel
+        const int big = (int)lds_max;
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&co_rowvec_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, big);
+#define SWN_CO_ATTR(KN) if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&KN), hipFuncAttributeMaxDynamicSharedMemorySize, big)
+        SWN_CO_ATTR((co_layer_kernel<SWN_KIND_LAPLACE, 4, 8>));  SWN_CO_ATTR((co_layer_kernel<SWN_KIND_SOFTMAX, 4, 8>));
+        SWN_CO_ATTR((co_layer_kernel<SWN_KIND_LAPLACE, 12, 3>)); SWN_CO_ATTR((co_layer_kernel<SWN_KIND_SOFTMAX, 12, 3>));
+        SWN_CO_ATTR((co_layer_kernel<SWN_KIND_LAPLACE, 16, 2>)); SWN_CO_ATTR((co_layer_kernel<SWN_KIND_SOFTMAX, 16, 2>));
+#undef SWN_CO_ATTR
+        if (e != hipSuccess) { swn_set_error_detail("swn_decode(cohort): hipFuncSetAttribute", hipGetErrorString(e)); return SWN_E_LAUNCH; }
+    }
+    const int total = a.n_pro + n_steps;
+    for (int it = 0; it < total; ++it) {
+        if (lap) hipLaunchKernelGGL(co_in_kernel<SWN_KIND_LAPLACE>, dim3((g.H + 3) / 4, nco), dim3(256), 0, st, a, it);
+        else hipLaunchKernelGGL(co_in_kernel<SWN_KIND_SOFTMAX>, dim3((g.H + 3) / 4, nco), dim3(256), 0, st, a, it);
+        for (int l = 0; l < g.L; ++l) {
+            const dim3 lg((g.H + PW - 1) / PW, nco);
+#define SWN_CO_LAYER(IP, TP_)                                                                                       \
+            do {                                                                                                     \
+                if (lap) hipLaunchKernelGGL((co_layer_kernel<SWN_KIND_LAPLACE, IP, TP_>), lg, dim3(1024), lds_layer, st, a, l, it); \
+                else hipLaunchKernelGGL((co_layer_kernel<SWN_KIND_SOFTMAX, IP, TP_>), lg, dim3(1024), lds_layer, st, a, l, it);     \
+            } while (0)
+            if (ipw == 4) SWN_CO_LAYER(4, 8);
+            else if (ipw == 12) SWN_CO_LAYER(12, 3);
+            else SWN_CO_LAYER(16, 2);
+#undef SWN_CO_LAYER
+        }
+        if (it < a.n_pro) continue;
+        // row lengths are the padded ones (multiples of 4; the padding of weights and activations is zero)
+        hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.S + RW - 1) / RW, nco), dim3(1024), lds_rv(g.L * g.Hp), st, a, a.y.wsk, g.L * g.Hp, a.y.bsk,
+                           g.S, g.L * g.Hp, a.o_hcat, a.o_skip, 1);
+        hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.O1 + RW - 1) / RW, nco), dim3(1024), lds_rv(g.Sp), st, a, a.y.w1, g.Sp, a.y.b1,
+                           g.O1, g.Sp, a.o_skip, a.o_o1, 1);
+        hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.NO + RW - 1) / RW, nco), dim3(1024), lds_rv(g.O1p), st, a, a.y.w2, g.O1p, a.y.b2,
+                           g.NO, g.O1p, a.o_o1, a.o_o2, 0);
+        if (lap) hipLaunchKernelGGL(co_tail_kernel<SWN_KIND_LAPLACE>, dim3(nco), dim3(256), 0, st, a, it);
+        else hipLaunchKernelGGL(co_tail_kernel<SWN_KIND_SOFTMAX>, dim3(nco), dim3(256), 0, st, a, it);
+    }
+    return swn_launch_status("swn_decode(cohort)");
+}

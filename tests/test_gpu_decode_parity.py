@@ -21,8 +21,8 @@ TOL_FREE = 1e-5
 TOL_TF = 2e-6
 BIG_STEPS = 400          # REF6 fixtures: first steps only (generic kernel streams 15-24 MB/step)
 
-LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith("g5_drop")]
-SMX = [n for n in golden_names() if "softmax" in n and not n.startswith("g5_drop")]
+LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_"))]
+SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_"))]
 
 
 def _net(cfg, d):
@@ -31,8 +31,9 @@ def _net(cfg, d):
 
 
 def _variants(cfg):
-    """1 generic persistent, 3 stepped multi-launch, 0 auto (BL6 fast kernel / stepped for REF6)"""
-    return [1, 3, 0]
+    """1 generic persistent, 3 stepped multi-launch, 4 cohort (lanes = utterances), 0 auto (BL6 fast kernel /
+    stepped or cohort for REF6)"""
+    return [1, 3, 4, 0]
 
 
 @pytest.mark.parametrize("name", LAP)

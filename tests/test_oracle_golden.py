@@ -24,8 +24,8 @@ def _params(cfg, d):
     return cpu_ref.as_params(sd)
 
 
-LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith("g5_drop")]
-SMX = [n for n in golden_names() if "softmax" in n and not n.startswith("g5_drop")]
+LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_"))]
+SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_"))]
 
 
 def test_fixture_inventory():
