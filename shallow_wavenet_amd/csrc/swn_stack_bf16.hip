@@ -666,13 +666,26 @@ BfOffsets bf_offsets(const SwnGeom& g) {
 
 }  // namespace
 
+// large geometries (H a multiple of 64 beyond the BL6 class): tiled bf16 GEMM stack, csrc/swn_stack_bf16g.hip
+int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g);
+size_t swn_bf16g_weight_bytes(const SwnGeom& g);
+int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf, hipStream_t st);
+size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
+int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const float* audio,
+                      int batch, int n_frames, void* work, float* out, hipStream_t st);
+
 extern "C" size_t swn_bf16_weight_bytes(const swn_net_desc* d) {
-    SwnGeom g; if (bf_geom(d, &g) < 0) return 0;
+    SwnGeom g;
+    if (bf_geom(d, &g) < 0) return swn_bf16g_geom(d, &g) < 0 ? 0 : swn_bf16g_weight_bytes(g);
     return bf_offsets(g).total * sizeof(unsigned short);
 }
 
 extern "C" int swn_pack_bf16(const swn_net_desc* d, const float* packed, void* wbf_, void* stream_) {
     SwnGeom g; int rc = bf_geom(d, &g);
+    if (rc == SWN_E_UNSUPPORTED && swn_bf16g_geom(d, &g) == SWN_OK) {
+        if (!packed || !wbf_) return SWN_E_BADARG;
+        return swn_bf16g_pack(g, packed, wbf_, (hipStream_t)stream_);
+    }
     if (rc < 0) return rc;
     if (!packed || !wbf_) return SWN_E_BADARG;
     SwnLayout y; swn_make_layout(&g, &y);
@@ -692,7 +705,13 @@ extern "C" int swn_pack_bf16(const swn_net_desc* d, const float* packed, void* w
 }
 
 extern "C" size_t swn_forward_bf16_work_bytes(const swn_net_desc* d, int batch, int n_frames) {
-    SwnGeom g; if (bf_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    SwnGeom g;
+    if (batch < 1 || n_frames < 1) return 0;
+    if (bf_geom(d, &g) < 0) {
+        if (swn_bf16g_geom(d, &g) < 0) return 0;
+        const long Tpg = (long)n_frames * g.U - 2 * g.seg + 1;
+        return Tpg < 1 ? 0 : swn_bf16g_work_bytes(g, batch, Tpg);
+    }
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
     if (Tp < 1) return 0;
     return (size_t)(g.L + 1) * batch * Tp * H * sizeof(unsigned short);
@@ -701,6 +720,11 @@ extern "C" size_t swn_forward_bf16_work_bytes(const swn_net_desc* d, int batch, 
 extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, const void* wbf, const float* cond,
                                 const float* audio, int batch, int n_frames, void* work, float* out, void* stream_) {
     SwnGeom g; int rc = bf_geom(d, &g);
+    if (rc == SWN_E_UNSUPPORTED && swn_bf16g_geom(d, &g) == SWN_OK) {
+        if (!packed || !wbf || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+        if ((long)n_frames * g.U - 2 * g.seg + 1 < 1) return SWN_E_BADARG;
+        return swn_bf16g_forward(g, packed, wbf, cond, audio, batch, n_frames, work, out, (hipStream_t)stream_);
+    }
     if (rc < 0) return rc;
     if (!packed || !wbf || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;

@@ -1,0 +1,276 @@
+// bf16 MFMA teacher-forced stack for the LARGE geometries (reference-shipped REF6: H = 192 / 256, K = 7): the
+// MFMA-bound side of BASELINE cfg4 (AI ~ 630 flop/B at REF6).  The BL6 class (H = 64, K = 2: HBM-bound) has its own
+// register-resident kernels in swn_stack_bf16.hip; here every layer is a real GEMM
+//     D[2H rows][positions] = Wd[2H][K*H] . Xcol[K*H][positions],  Xcol(tap, i; t) = h[t - (K-1-tap) dil][i]
+// and so are skip (K = L*H), out_1 and out_2.  One tiled kernel serves them all:
+//   * workgroup tile 128 rows x 128 positions, 4 waves of 64 x 64 (16 accumulators of v_mfma_f32_16x16x32_bf16),
+//     k-tiles of 32 staged in LDS (rows padded to 80 B: conflict-free 16-byte fragment reads), the next k-tile's
+//     global loads in flight under the MFMAs of the current one;
+//   * activations stay bf16 time-major [layer][b][t][H] (a B tile row = 32 consecutive channels of one position
+//     = one 64-byte segment); the causal shift of a tap is an index offset, positions before 0 read zeros;
+//   * layer epilogue = the gate: the tile's rows are ordered [gate 16 | cand 16 | gate 16 | cand 16] per wave so a
+//     lane holds the gate and candidate pre-activations of the same 8 channels; hoisted conditioning, sigmoid /
+//     tanh and the highway mix in fp32, bf16 store.  Other epilogues: bias + relu -> bf16 time-major (skip,
+//     out_1), bias -> fp32 (B, n_out, Tp) (out_2).
+// fp32 accumulation everywhere; parameters are the bf16 roundings of the packed fp32 weights.
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include "swn_geom.hpp"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+constexpr int TM = 128, TN = 128, TK = 32;
+constexpr int PITCH = 40;        // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
+
+__device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
+
+enum { EPI_GATE = 0, EPI_RELU_BF16 = 1, EPI_F32 = 2 };
+
+struct GemmArgs {
+    const unsigned short* A; int M, Kd;            // bf16 [M][Kd] row-major
+    const unsigned short* src; size_t blk_stride;  // B operand: block blk, channel i, position t:
+    int KB, nblk, shift0, shift_step;              //   src[blk*blk_stride + (b*Tp + t - (shift0 - blk*shift_step))*KB + i]
+    int Tp, B;
+    // epilogues
+    const float* P; const float* bias;             // packed fp32 parameters; bias of plain GEMMs
+    unsigned short* out_bf; int out_ld;            // RELU_BF16: out_bf[(b*Tp + t)*out_ld + m]
+    float* out_f; int NO;                          // F32: out_f[(b*NO + m)*Tp + t]
+    // gate
+    const unsigned short* hprev; unsigned short* hnext; const float* cond;
+    size_t o_bd, o_bx, o_wup;
+    int H, l, seg, U, Tf, N, coff;
+};
+
+template <int EPI>
+__global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned short As[TM * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int t0 = blockIdx.x * TN, m0 = blockIdx.y * TM, b = blockIdx.z;
+    // tile row -> matrix row
+    auto rowmap = [&](int tr) -> int {
+        if (EPI != EPI_GATE) return m0 + tr;
+        const int c0 = blockIdx.y * 64, wmr = tr >> 6, mt = (tr & 63) >> 4, r = tr & 15;
+        const int ch = c0 + 32 * wmr + 16 * (mt >> 1) + r;
+        return ch < a.H ? (mt & 1) * a.H + ch : -1;
+    };
+    // staging: thread -> (row = tid/2, half = tid%2): 2 x 16 bytes of a 64-byte k-tile row, for A and for B
+    const int sr = tid >> 1, sh = tid & 1;
+    const int arow = rowmap(sr);
+    const bool aok = arow >= 0 && arow < a.M;
+    const unsigned short* ap = a.A + (size_t)(aok ? arow : 0) * a.Kd + 16 * sh;
+    const int tpos = t0 + sr;
+    const int ktiles_per_blk = a.KB / TK, nk = a.nblk * ktiles_per_blk;
+    uint4 ra[2], rb[2];
+    auto fetch = [&](int kt) {
+        const int blk = kt / ktiles_per_blk, kin = (kt - blk * ktiles_per_blk) * TK;
+        const uint4* pa = reinterpret_cast<const uint4*>(ap + (size_t)kt * TK);
+        ra[0] = aok ? pa[0] : make_uint4(0, 0, 0, 0);
+        ra[1] = aok ? pa[1] : make_uint4(0, 0, 0, 0);
+        const int ts = tpos - (a.shift0 - blk * a.shift_step);
+        if (tpos < a.Tp && ts >= 0) {
+            const uint4* pb = reinterpret_cast<const uint4*>(a.src + (size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 16 * sh);
+            rb[0] = pb[0]; rb[1] = pb[1];
+        } else { rb[0] = make_uint4(0, 0, 0, 0); rb[1] = rb[0]; }
+    };
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    fetch(0);
+    for (int kt = 0; kt < nk; ++kt) {
+        *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh) = ra[0];
+        *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh + 8) = ra[1];
+        *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh) = rb[0];
+        *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh + 8) = rb[1];
+        __syncthreads();
+        if (kt + 1 < nk) fetch(kt + 1);
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            af[i] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
+            bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        __syncthreads();
+    }
+    // accumulator element (i, j, r): tile row 64 wm + 16 i + 4 (lane/16) + r, tile column 64 wn + 16 j + lane%16
+    const int g4 = lane >> 4, n = lane & 15;
+    if (EPI == EPI_GATE) {
+        const float* P = a.P;
+        const int H = a.H, H2 = 2 * a.H, l = a.l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 64 * wn + 16 * j + n;
+            if (t >= a.Tp) continue;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const int ch = blockIdx.y * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
+                if (ch >= H) continue;
+                float gz[4], gc[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { gz[r] = P[a.o_bx + (size_t)l * H2 + ch + r]; gc[r] = P[a.o_bx + (size_t)l * H2 + H + ch + r]; }
+                for (int s = 0; s < a.seg; ++s) {
+                    const int tt = t + s + a.coff;
+                    int f = tt / a.U; const int jj = tt - f * a.U;
+                    f = f < a.Tf ? f : a.Tf - 1;
+                    const float wu = P[a.o_wup + jj];
+                    const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)(l * a.seg + s) * H2 + ch;
+                    const float4 cz = *reinterpret_cast<const float4*>(cr), cc = *reinterpret_cast<const float4*>(cr + H);
+                    gz[0] = fmaf(wu, cz.x, gz[0]); gz[1] = fmaf(wu, cz.y, gz[1]); gz[2] = fmaf(wu, cz.z, gz[2]); gz[3] = fmaf(wu, cz.w, gz[3]);
+                    gc[0] = fmaf(wu, cc.x, gc[0]); gc[1] = fmaf(wu, cc.y, gc[1]); gc[2] = fmaf(wu, cc.z, gc[2]); gc[3] = fmaf(wu, cc.w, gc[3]);
+                }
+                const uint2 hp2 = *reinterpret_cast<const uint2*>(a.hprev + ((size_t)b * a.Tp + t) * H + ch);
+                const float hp[4] = {bf2f((unsigned short)(hp2.x & 0xffff)), bf2f((unsigned short)(hp2.x >> 16)),
+                                     bf2f((unsigned short)(hp2.y & 0xffff)), bf2f((unsigned short)(hp2.y >> 16))};
+                unsigned short hv[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z = sigm(gz[r] * (acc[2 * p][j][r] + P[a.o_bd + (size_t)l * H2 + ch + r]));
+                    const float c = tanhf(gc[r] * (acc[2 * p + 1][j][r] + P[a.o_bd + (size_t)l * H2 + H + ch + r]));
+                    hv[r] = f2bf((1.f - z) * c + z * hp[r]);
+                }
+                uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
+                *reinterpret_cast<uint2*>(a.hnext + ((size_t)b * a.Tp + t) * H + ch) = o;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 64 * wn + 16 * j + n;
+            if (t >= a.Tp) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * g4;
+                if (EPI == EPI_RELU_BF16) {
+                    if (m >= a.M) continue;                   // M is a multiple of 4 here
+                    unsigned short hv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[r] = f2bf(fmaxf(acc[i][j][r] + a.bias[m + r], 0.f));
+                    uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
+                    *reinterpret_cast<uint2*>(a.out_bf + ((size_t)b * a.Tp + t) * a.out_ld + m) = o;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (m + r < a.NO) a.out_f[((size_t)b * a.NO + m + r) * a.Tp + t] = acc[i][j][r] + a.bias[m + r];
+                }
+            }
+        }
+    }
+}
+
+// fp32 [rows][ld] (first `cols` of each row) -> bf16 [rows][cols]
+__global__ void bf16g_convert_kernel(const float* __restrict__ src, int ld, int rows, int cols, unsigned short* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)rows * cols) return;
+    const int r = (int)(e / cols), c = (int)(e - (size_t)r * cols);
+    dst[e] = f2bf(src[(size_t)r * ld + c]);
+}
+
+// input layer: h0[b][t][o] = softsign(cb + sum_k (cv[k][o] * audio[ai - (K-1-k)] + cc[k][o]))   (Laplace; cswnv_shift1.py:203-206)
+__global__ __launch_bounds__(256) void bf16g_input_kernel(const float* __restrict__ P, size_t o_cb, size_t o_cv, size_t o_cc,
+                                                          const float* __restrict__ audio, unsigned short* __restrict__ h0,
+                                                          int H, int K, int seg, int Tp) {
+    const int o = threadIdx.x, b = blockIdx.y;
+    const float* au = audio + (size_t)b * (Tp + seg - 1);
+    for (int i = 0; i < 16; ++i) {
+        const int t = blockIdx.x * 16 + i;
+        if (t >= Tp || o >= H) break;
+        const int ai = t + seg - 1;
+        float acc = P[o_cb + o];
+        for (int k = 0; k < K; ++k) {
+            const int r = ai - (K - 1 - k);
+            if (r >= 0) acc += fmaf(P[o_cv + (size_t)k * H + o], au[r], P[o_cc + (size_t)k * H + o]);
+        }
+        h0[((size_t)b * Tp + t) * H + o] = f2bf(acc / (1.f + fabsf(acc)));
+    }
+}
+
+struct GOff { size_t wd, wsk, w1, w2, total; };
+GOff g_offsets(const SwnGeom& g) {
+    GOff o;
+    o.wd = 0;
+    o.wsk = o.wd + (size_t)g.L * 2 * g.H * g.K * g.H;
+    o.w1 = o.wsk + (size_t)g.S * g.L * g.H;
+    o.w2 = o.w1 + (size_t)g.O1 * g.S;
+    o.total = o.w2 + (size_t)g.NO * g.O1;
+    return o;
+}
+
+}  // namespace
+
+// geometry class of this file: Laplace, H a multiple of 64 (row tiles of 64 channels, k-tiles of 32), S and O1
+// multiples of 32, at most 256 input-layer channels per block
+int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g) {
+    int rc = swn_make_geom(d, g);
+    if (rc < 0) return rc;
+    if (g->kind != SWN_KIND_LAPLACE || g->H % 64 != 0 || g->H > 256 || g->S % 32 != 0 || g->O1 % 32 != 0) return SWN_E_UNSUPPORTED;
+    return SWN_OK;
+}
+
+size_t swn_bf16g_weight_bytes(const SwnGeom& g) { return g_offsets(g).total * sizeof(unsigned short); }
+
+int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf_, hipStream_t st) {
+    SwnLayout y; swn_make_layout(&g, &y);
+    const GOff o = g_offsets(g);
+    unsigned short* wbf = reinterpret_cast<unsigned short*>(wbf_);
+    auto conv = [&](size_t src_off, int ld, int rows, int cols, size_t dst_off) {
+        const size_t n = (size_t)rows * cols;
+        hipLaunchKernelGGL(bf16g_convert_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, packed + src_off, ld, rows, cols, wbf + dst_off);
+    };
+    conv(y.wd, g.K * g.Hp, g.L * 2 * g.H, g.K * g.H, o.wd);      // Hp == H in this class
+    conv(y.wsk, g.L * g.Hp, g.S, g.L * g.H, o.wsk);
+    conv(y.w1, g.Sp, g.O1, g.S, o.w1);
+    conv(y.w2, g.O1p, g.NO, g.O1, o.w2);
+    return swn_launch_status("swn_pack_bf16");
+}
+
+size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp) {
+    return ((size_t)(g.L + 1) * g.H + g.S + g.O1) * batch * Tp * sizeof(unsigned short);
+}
+
+int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, const float* cond, const float* audio,
+                      int batch, int n_frames, void* work, float* out, hipStream_t st) {
+    SwnLayout y; swn_make_layout(&g, &y);
+    const GOff o = g_offsets(g);
+    const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
+    const unsigned short* wbf = reinterpret_cast<const unsigned short*>(wbf_);
+    unsigned short* hs = reinterpret_cast<unsigned short*>(work);
+    const size_t lstride = (size_t)batch * Tp * g.H;
+    unsigned short* skipb = hs + (size_t)(g.L + 1) * lstride;
+    unsigned short* o1b = skipb + (size_t)batch * Tp * g.S;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bf16g_input_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
+                       audio, hs, g.H, g.K, g.seg, (int)Tp);
+    GemmArgs a = {};
+    a.Tp = (int)Tp; a.B = batch; a.P = packed; a.cond = cond; a.H = g.H; a.seg = g.seg; a.U = g.U; a.Tf = n_frames; a.N = g.N;
+    a.coff = g.seg; a.o_bd = y.bd; a.o_bx = y.bx; a.o_wup = y.wup;
+    const unsigned tx = (unsigned)((Tp + TN - 1) / TN);
+    for (int l = 0; l < g.L; ++l) {
+        a.A = wbf + o.wd + (size_t)l * 2 * g.H * g.K * g.H; a.M = 2 * g.H; a.Kd = g.K * g.H;
+        a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K;
+        a.shift0 = (g.K - 1) * g.dil[l]; a.shift_step = g.dil[l];
+        a.hprev = hs + (size_t)l * lstride; a.hnext = hs + (size_t)(l + 1) * lstride; a.l = l;
+        hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_GATE>, dim3(tx, g.H / 64, batch), dim3(256), 0, st, a);
+    }
+    // skip = relu(Wsk . [h_1 .. h_L] + b)
+    a.A = wbf + o.wsk; a.M = g.S; a.Kd = g.L * g.H; a.src = hs + lstride; a.blk_stride = lstride; a.KB = g.H; a.nblk = g.L;
+    a.shift0 = 0; a.shift_step = 0; a.bias = packed + y.bsk; a.out_bf = skipb; a.out_ld = g.S;
+    hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_RELU_BF16>, dim3(tx, (g.S + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    a.A = wbf + o.w1; a.M = g.O1; a.Kd = g.S; a.src = skipb; a.blk_stride = 0; a.KB = g.S; a.nblk = 1;
+    a.bias = packed + y.b1; a.out_bf = o1b; a.out_ld = g.O1;
+    hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_RELU_BF16>, dim3(tx, (g.O1 + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    a.A = wbf + o.w2; a.M = g.NO; a.Kd = g.O1; a.src = o1b; a.KB = g.O1; a.nblk = 1;
+    a.bias = packed + y.b2; a.out_f = out; a.NO = g.NO;
+    hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_F32>, dim3(tx, (g.NO + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    return swn_launch_status("swn_forward_bf16");
+}

@@ -164,7 +164,7 @@ class HipNet:
         d = ctypes.byref(self.desc)
         nbytes = L.swn_bf16_weight_bytes(d)
         if nbytes == 0:
-            raise RuntimeError("bf16 stack kernels are built for the BL6-class Laplace geometry only")
+            raise RuntimeError("bf16 stack kernels are built for the BL6-class and the H%64==0 Laplace geometries only")
         if cond is None:
             cond = self.frontend(aux)
         B, Tf = cond.shape[0], cond.shape[1]

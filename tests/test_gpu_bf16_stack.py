@@ -47,3 +47,22 @@ def test_bf16_unsupported_geometry_is_reported(gpu_ok):
     net = HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=2), "cuda:0")
     with pytest.raises(RuntimeError, match="BL6-class"):
         net.forward_bf16(torch.zeros(1, cfg.n_aux, 4), torch.zeros(1, 1, 4 * cfg.U - 1))
+
+
+@pytest.mark.parametrize("seg,lpc,B,Tf", [(1, 4, 2, 9), (5, 4, 1, 7)])
+def test_bf16_gemm_stack_for_large_geometries_tracks_the_fp32_kernels(gpu_ok, seg, lpc, B, Tf):
+    """reference run.sh geometry (H=192, K=7, 3x2 layers: csrc/swn_stack_bf16g.hip) against the fp32 parity kernels:
+    positions before and after the receptive field, ragged tile tails (Tp is not a multiple of 128), batch > 1.
+    Tolerance as for the BL6 class: 3e-3 of the output scale (bf16 operands, fp32 accumulation)."""
+    cfg = C.ref6_laplace(seg, lpc)
+    sd = synth_state_dict(cfg, seed=4, flavor="trained")
+    net = HipNet.from_state_dict(cfg, sd, "cuda:0")
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf))
+    T = Tf * cfg.U
+    audio = torch.rand(B, 1, T - seg, generator=torch.Generator().manual_seed(1)) * 1.6 - 0.8
+    r32, _ = net.forward(aux, audio)
+    r16 = net.forward_bf16(aux, audio)
+    assert r16.shape == r32.shape
+    d = (r32 - r16).abs()
+    assert float(d.max()) <= 3e-3 * max(1.0, float(r32.abs().max())), float(d.max())
+    assert float(d.mean()) <= 3e-4 * max(1.0, float(r32.abs().max()))
