@@ -33,7 +33,7 @@ enum { EPI_GATE = 0, EPI_RELU_BF16 = 1, EPI_F32 = 2 };
 
 struct GemmArgs {
     const unsigned short* A; int M, Kd;            // bf16 [M][Kd] row-major
-    const unsigned short* src; size_t blk_stride;  // B operand: block blk, channel i, position t:
+    const unsigned short* src; size_t blk_stride; size_t src_bytes;  // B operand (src_bytes < 2 GiB): block blk, channel i, position t:
     int KB, nblk, shift0, shift_step;              //   src[blk*blk_stride + (b*Tp + t - (shift0 - blk*shift_step))*KB + i]
     int Tp, B;
     // epilogues
@@ -63,45 +63,58 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
     const int sr = tid >> 1, sh = tid & 1;
     const int arow = rowmap(sr);
     const bool aok = arow >= 0 && arow < a.M;
-    const unsigned short* ap = a.A + (size_t)(aok ? arow : 0) * a.Kd + 16 * sh;
     const int tpos = t0 + sr;
     const int ktiles_per_blk = a.KB / TK, nk = a.nblk * ktiles_per_blk;
-    uint4 ra[2], rb[2];
-    auto fetch = [&](int kt) {
+    constexpr int NST = 3;                      // k-tiles in flight per thread (register stages)
+    uint4 ra[NST][2], rb[NST][2];
+    // branch-free AND select-free: operands come through buffer resources, and everything that must read as zero
+    // (a k-tile past the end of the padded k loop, a row past M, a position outside the sequence) is an
+    // out-of-range offset.  Any branch around the loads - or any use of a loaded value right behind its load -
+    // makes the compiler drain the whole prefetch queue (vmcnt(0)) at every k-tile.
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.A), 0, (unsigned)((size_t)a.M * a.Kd * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.src), 0, (unsigned)a.src_bytes, 0x00020000);
+    constexpr unsigned OOB = 0x80000000u;
+    const unsigned a_off = aok ? (unsigned)(((size_t)arow * a.Kd + 16 * sh) * 2) : OOB;
+    auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
+    auto fetch = [&](int kt, uint4 (&qa)[2], uint4 (&qb)[2]) {
+        const bool live = kt < nk;
         const int blk = kt / ktiles_per_blk, kin = (kt - blk * ktiles_per_blk) * TK;
-        const uint4* pa = reinterpret_cast<const uint4*>(ap + (size_t)kt * TK);
-        ra[0] = aok ? pa[0] : make_uint4(0, 0, 0, 0);
-        ra[1] = aok ? pa[1] : make_uint4(0, 0, 0, 0);
+        const unsigned oa = (live && aok) ? a_off + (unsigned)kt * (TK * 2) : OOB;
         const int ts = tpos - (a.shift0 - blk * a.shift_step);
-        if (tpos < a.Tp && ts >= 0) {
-            const uint4* pb = reinterpret_cast<const uint4*>(a.src + (size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 16 * sh);
-            rb[0] = pb[0]; rb[1] = pb[1];
-        } else { rb[0] = make_uint4(0, 0, 0, 0); rb[1] = rb[0]; }
+        const bool bok = live && tpos < a.Tp && ts >= 0;
+        const unsigned ob = bok ? (unsigned)(((size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 16 * sh) * 2) : OOB;
+        qa[0] = ld16(rA, oa); qa[1] = ld16(rA, oa + 16u);
+        qb[0] = ld16(rB, ob); qb[1] = ld16(rB, ob + 16u);
     };
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    fetch(0);
-    for (int kt = 0; kt < nk; ++kt) {
-        *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh) = ra[0];
-        *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh + 8) = ra[1];
-        *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh) = rb[0];
-        *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh + 8) = rb[1];
-        __syncthreads();
-        if (kt + 1 < nk) fetch(kt + 1);
-        bf16x8 af[4], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            af[i] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
-            bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
+    for (int u = 0; u < NST; ++u) fetch(u, ra[u], rb[u]);
+    for (int kt0 = 0; kt0 < nk; kt0 += NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {
+            const int kt = kt0 + u;                          // tiles past nk are all-zero operands: no branch in the loop
+            *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh) = ra[u][0];
+            *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh + 8) = ra[u][1];
+            *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh) = rb[u][0];
+            *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh + 8) = rb[u][1];
+            __syncthreads();
+            fetch(kt + NST, ra[u], rb[u]);             // refill the stage just consumed: NST k-tiles of loads in flight
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                af[i] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
+                bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            __syncthreads();
         }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-        __syncthreads();
     }
     // accumulator element (i, j, r): tile row 64 wm + 16 i + 4 (lane/16) + r, tile column 64 wn + 16 j + lane%16
     const int g4 = lane >> 4, n = lane & 15;
@@ -248,6 +261,8 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
     const size_t lstride = (size_t)batch * Tp * g.H;
     unsigned short* skipb = hs + (size_t)(g.L + 1) * lstride;
     unsigned short* o1b = skipb + (size_t)batch * Tp * g.S;
+    // 32-bit buffer offsets: every GEMM operand must stay below 2 GiB
+    if ((size_t)g.L * lstride * 2 >= (1ull << 31) || (size_t)batch * Tp * (g.S > g.O1 ? g.S : g.O1) * 2 >= (1ull << 31)) return SWN_E_UNSUPPORTED;
     (void)hipGetLastError();
     hipLaunchKernelGGL(bf16g_input_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
                        audio, hs, g.H, g.K, g.seg, (int)Tp);
@@ -257,19 +272,20 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
     const unsigned tx = (unsigned)((Tp + TN - 1) / TN);
     for (int l = 0; l < g.L; ++l) {
         a.A = wbf + o.wd + (size_t)l * 2 * g.H * g.K * g.H; a.M = 2 * g.H; a.Kd = g.K * g.H;
-        a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K;
+        a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K; a.src_bytes = lstride * 2;
         a.shift0 = (g.K - 1) * g.dil[l]; a.shift_step = g.dil[l];
         a.hprev = hs + (size_t)l * lstride; a.hnext = hs + (size_t)(l + 1) * lstride; a.l = l;
         hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_GATE>, dim3(tx, g.H / 64, batch), dim3(256), 0, st, a);
     }
     // skip = relu(Wsk . [h_1 .. h_L] + b)
     a.A = wbf + o.wsk; a.M = g.S; a.Kd = g.L * g.H; a.src = hs + lstride; a.blk_stride = lstride; a.KB = g.H; a.nblk = g.L;
+    a.src_bytes = (size_t)g.L * lstride * 2;
     a.shift0 = 0; a.shift_step = 0; a.bias = packed + y.bsk; a.out_bf = skipb; a.out_ld = g.S;
     hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_RELU_BF16>, dim3(tx, (g.S + TM - 1) / TM, batch), dim3(256), 0, st, a);
-    a.A = wbf + o.w1; a.M = g.O1; a.Kd = g.S; a.src = skipb; a.blk_stride = 0; a.KB = g.S; a.nblk = 1;
+    a.A = wbf + o.w1; a.M = g.O1; a.Kd = g.S; a.src = skipb; a.blk_stride = 0; a.KB = g.S; a.nblk = 1; a.src_bytes = (size_t)batch * Tp * g.S * 2;
     a.bias = packed + y.b1; a.out_bf = o1b; a.out_ld = g.O1;
     hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_RELU_BF16>, dim3(tx, (g.O1 + TM - 1) / TM, batch), dim3(256), 0, st, a);
-    a.A = wbf + o.w2; a.M = g.NO; a.Kd = g.O1; a.src = o1b; a.KB = g.O1; a.nblk = 1;
+    a.A = wbf + o.w2; a.M = g.NO; a.Kd = g.O1; a.src = o1b; a.KB = g.O1; a.nblk = 1; a.src_bytes = (size_t)batch * Tp * g.O1 * 2;
     a.bias = packed + y.b2; a.out_f = out; a.NO = g.NO;
     hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_F32>, dim3(tx, (g.NO + TM - 1) / TM, batch), dim3(256), 0, st, a);
     return swn_launch_status("swn_forward_bf16");
