@@ -31,13 +31,28 @@ struct TimeGemm {
     int XT;                                         // X is valid on [0, XT) (0: same as T)
 };
 
-// 64(m) x 64(t) tile, BK = 16 over k = (tap, c); product on the matrix cores (swn_mma.hpp).
+// Operand loads of the tiled kernels: through buffer resources with 32-bit byte offsets.  Whatever must read as
+// zero (k past the end, a row past M, a position outside [0, T)) is the out-of-range offset, so the loads need
+// neither branches nor selects - either would make the compiler drain the prefetch queue (s_waitcnt vmcnt(0)) at
+// every k-tile, which is what these kernels were bound by.  Every operand (per batch item) must be < 2 GiB.
+constexpr unsigned SWN_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
+// 64(m) x 64(t) tile, BK = 16 over k = (tap, c); product on the matrix cores (swn_mma.hpp); NST k-tiles of operand
+// loads in flight per thread.
+template <bool XMUL>
 __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
     __shared__ float As[16][SWN_MMA_PITCH];
     __shared__ float Bs[16][SWN_MMA_PITCH];
     const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float* Xb = g.X + (size_t)b * g.x_sb;
+    const __amdgpu_buffer_rsrc_t rA = rsrc_of(g.A), rX = rsrc_of(g.X + (size_t)b * g.x_sb);
+    const __amdgpu_buffer_rsrc_t rM = rsrc_of(XMUL ? g.xmul + (size_t)b * g.xm_sb : g.A);
     const int Kd = g.taps * g.KC;
     swn_f32x4 acc[4] = {};
     // (tap, c) of the k index each thread loads, advanced by 16 per k-tile without divisions:
@@ -49,38 +64,41 @@ __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
     for (int i = 0; i < 4; ++i) { const int kk = (tid >> 6) + 4 * i; tapB[i] = kk / g.KC; cB[i] = kk - tapB[i] * g.KC; }
     const int XT = g.XT ? g.XT : g.T;
     const bool tok = t0 + tt < g.T;
-    float ra[4], rb[4];
-    auto fetch = [&](int k0) {       // global -> registers (the LDS stores follow the MFMAs of the previous tile)
+    constexpr int NST = 3;
+    float ra[NST][4], rb[NST][4], rm[NST][4];
+    auto fetch = [&](int k0, float (&qa)[4], float (&qb)[4], float (&qm)[4]) {
         const bool ka = k0 + kka < Kd;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + (tid >> 4) + 16 * i;
-            ra[i] = (ka && m < g.M) ? g.A[m * g.a_sm + tapA * g.a_stap + cA * g.a_sc] : 0.f;
+            qa[i] = bld1(rA, (ka && m < g.M) ? (unsigned)((m * g.a_sm + tapA * g.a_stap + cA * g.a_sc) * 4) : SWN_OOB);
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            float v = 0.f;
-            if (k0 + (tid >> 6) + 4 * i < Kd) {
-                const int ts = t0 + tt + g.sgn * (tapB[i] - g.center) * g.dil;
-                if (ts >= 0 && ts < XT && tok) {
-                    v = Xb[cB[i] * g.x_sc + ts * g.x_st];
-                    if (g.xmul) v *= g.xmul[(size_t)b * g.xm_sb + (size_t)cB[i] * g.xm_sc + ts];
-                }
-            }
-            rb[i] = v;
+            const int ts = t0 + tt + g.sgn * (tapB[i] - g.center) * g.dil;
+            const bool ok = k0 + (tid >> 6) + 4 * i < Kd && ts >= 0 && ts < XT && tok;
+            qb[i] = bld1(rX, ok ? (unsigned)((cB[i] * g.x_sc + ts * g.x_st) * 4) : SWN_OOB);
+            if (XMUL) qm[i] = bld1(rM, ok ? (unsigned)(((size_t)cB[i] * g.xm_sc + ts) * 4) : SWN_OOB);
         }
         cA += 16; while (cA >= g.KC) { cA -= g.KC; ++tapA; }
 #pragma unroll
         for (int i = 0; i < 4; ++i) { cB[i] += 16; while (cB[i] >= g.KC) { cB[i] -= g.KC; ++tapB[i]; } }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < Kd; k0 += 16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { As[kka][(tid >> 4) + 16 * i] = ra[i]; Bs[(tid >> 6) + 4 * i][tt] = rb[i]; }
-        __syncthreads();
-        if (k0 + 16 < Kd) fetch(k0 + 16);          // next tile's loads fly under this tile's MFMAs
-        swn_mma_64x64x16(As, Bs, acc, lane, w);
-        __syncthreads();
+    for (int u = 0; u < NST; ++u) fetch(16 * u, ra[u], rb[u], rm[u]);
+    for (int k0 = 0; k0 < Kd; k0 += 16 * NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {                 // tiles past Kd hold zeros: no branch inside the loop
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                As[kka][(tid >> 4) + 16 * i] = ra[u][i];
+                Bs[(tid >> 6) + 4 * i][tt] = XMUL ? rb[u][i] * rm[u][i] : rb[u][i];
+            }
+            __syncthreads();
+            fetch(k0 + 16 * (u + NST), ra[u], rb[u], rm[u]);
+            swn_mma_64x64x16(As, Bs, acc, lane, w);
+            __syncthreads();
+        }
     }
     const int t = t0 + swn_mma_col(lane, w);
     if (t >= g.T) return;
@@ -346,7 +364,8 @@ __global__ __launch_bounds__(256) void laplace_head_bwd_kernel(const float* __re
 size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
 void launch_time(const TimeGemm& g, int B, hipStream_t st) {
-    hipLaunchKernelGGL(time_gemm_kernel, dim3((g.T + 63) / 64, (g.M + 63) / 64, B), dim3(256), 0, st, g);
+    if (g.xmul) { hipLaunchKernelGGL(time_gemm_kernel<true>, dim3((g.T + 63) / 64, (g.M + 63) / 64, B), dim3(256), 0, st, g); return; }
+    hipLaunchKernelGGL(time_gemm_kernel<false>, dim3((g.T + 63) / 64, (g.M + 63) / 64, B), dim3(256), 0, st, g);
 }
 void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
     g.TS = 512;
