@@ -32,6 +32,22 @@ struct StArgs {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 __device__ __forceinline__ int pmod(int r, int m) { int t = r % m; return t < 0 ? t + m : t; }
+
+// Every launch of this chain is a handful of memory round trips, so the loads of a phase must all be in flight
+// together.  A conditional load (`ok ? *p : 0`) compiles to an exec-masked branch followed by s_waitcnt vmcnt(0):
+// the first version of these kernels paid 12-14 SERIAL round trips per launch (4.5-8 us).  Loads therefore go
+// through buffer resources with 32-bit byte offsets, and "not mine / past the end" is the out-of-range offset
+// (reads zero, no branch).  The packed parameters and the whole decode state must each stay below 2 GiB.
+constexpr unsigned ST_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 st_ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float st_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
 __device__ __forceinline__ float sum64(float v) {
     v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
     v += __shfl_xor(v, 2, 64);  v += __shfl_xor(v, 1, 64);
@@ -98,16 +114,16 @@ __global__ __launch_bounds__(64) void step_layer_kernel(const StArgs a, const in
     const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg, KH = K * Hp;
     const bool live = o < H;
     const float* P = a.P;
+    const __amdgpu_buffer_rsrc_t rP = st_rsrc(P), rS = st_rsrc(a.state);
     float4 wz[NI], wc[NI];
     {
-        const float* rz = P + a.y.wd + ((size_t)l * H2 + (live ? o : 0)) * KH;
-        const float* rc = rz + (size_t)H * KH;
+        const size_t rz = a.y.wd + ((size_t)l * H2 + (live ? o : 0)) * KH, rc = rz + (size_t)H * KH;
 #pragma unroll
         for (int pc = 0; pc < NI; ++pc) {
             const int idx = pc * 256 + lane * 4;
             const bool ok = live && idx < KH;
-            wz[pc] = ok ? *reinterpret_cast<const float4*>(rz + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
-            wc[pc] = ok ? *reinterpret_cast<const float4*>(rc + idx) : make_float4(0.f, 0.f, 0.f, 0.f);
+            wz[pc] = st_ld4(rP, ok ? (unsigned)((rz + idx) * 4) : ST_OOB);
+            wc[pc] = st_ld4(rP, ok ? (unsigned)((rc + idx) * 4) : ST_OOB);
         }
     }
     const int dil = g.dil[l], R = a.ring_len[l];
@@ -116,7 +132,22 @@ __global__ __launch_bounds__(64) void step_layer_kernel(const StArgs a, const in
     const int nb = a.B - b0 < BT ? a.B - b0 : BT;              // utterances of this tile, processed CONCURRENTLY:
     for (int j = 0; j < r.np; ++j) {                          // lane u finishes utterance b0+u
         const int q = r.q0 + j;
-        // epilogue operands first (independent of the mat-vec): their latency hides under it
+        float az[BT], ac[BT];
+#pragma unroll
+        for (int u = 0; u < BT; ++u) { az[u] = 0.f; ac[u] = 0.f; }
+        float4 xv[NI][BT];                                     // all activation loads of the position in flight at once
+#pragma unroll
+        for (int pc = 0; pc < NI; ++pc) {
+            const int idx = pc * 256 + lane * 4;
+            const int ic = idx < KH ? idx : 0;
+            const int tap = ic / Hp, i = ic - tap * Hp;
+            const size_t xo = a.ring_off[l] + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i;
+#pragma unroll
+            for (int u = 0; u < BT; ++u)
+                xv[pc][u] = st_ld4(rS, (idx < KH && u < nb) ? (unsigned)(((size_t)(b0 + u) * a.stride + xo) * 4) : ST_OOB);
+        }
+        // epilogue operands: issued behind the activation loads (this block is an exec-masked branch that waits for
+        // its own loads; placed first it would hold the activation loads back by a round trip)
         float gz = 0.f, gc = 0.f, bdz = 0.f, bdc = 0.f, hp = 0.f;
         if (lane < nb && live) {
             const int b = b0 + lane;
@@ -141,27 +172,16 @@ __global__ __launch_bounds__(64) void step_layer_kernel(const StArgs a, const in
                 gz += wa[o]; gc += wa[H + o];
             }
         }
-        float az[BT], ac[BT];
 #pragma unroll
-        for (int u = 0; u < BT; ++u) { az[u] = 0.f; ac[u] = 0.f; }
+        for (int pc = 0; pc < NI; ++pc)
 #pragma unroll
-        for (int pc = 0; pc < NI; ++pc) {
-            const int idx = pc * 256 + lane * 4;
-            if (idx < KH) {
-                const int tap = idx / Hp, i = idx - tap * Hp;
-                const size_t xo = a.ring_off[l] + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i;
-#pragma unroll
-                for (int u = 0; u < BT; ++u) {
-                    if (u < nb) {
-                        const float4 x = *reinterpret_cast<const float4*>(a.state + (size_t)(b0 + u) * a.stride + xo);
-                        az[u] = fmaf(wz[pc].x, x.x, az[u]); az[u] = fmaf(wz[pc].y, x.y, az[u]);
-                        az[u] = fmaf(wz[pc].z, x.z, az[u]); az[u] = fmaf(wz[pc].w, x.w, az[u]);
-                        ac[u] = fmaf(wc[pc].x, x.x, ac[u]); ac[u] = fmaf(wc[pc].y, x.y, ac[u]);
-                        ac[u] = fmaf(wc[pc].z, x.z, ac[u]); ac[u] = fmaf(wc[pc].w, x.w, ac[u]);
-                    }
-                }
+            for (int u = 0; u < BT; ++u) {
+                const float4 x = xv[pc][u];
+                az[u] = fmaf(wz[pc].x, x.x, az[u]); az[u] = fmaf(wz[pc].y, x.y, az[u]);
+                az[u] = fmaf(wz[pc].z, x.z, az[u]); az[u] = fmaf(wz[pc].w, x.w, az[u]);
+                ac[u] = fmaf(wc[pc].x, x.x, ac[u]); ac[u] = fmaf(wc[pc].y, x.y, ac[u]);
+                ac[u] = fmaf(wc[pc].z, x.z, ac[u]); ac[u] = fmaf(wc[pc].w, x.w, ac[u]);
             }
-        }
         float myz = 0.f, myc = 0.f;
 #pragma unroll
         for (int u = 0; u < BT; ++u) {
@@ -186,23 +206,33 @@ template <int BT>
 __global__ __launch_bounds__(64) void rowvec_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
                                                     int ni, int x_off, int y_off, int relu) {
     const int lane = threadIdx.x, row = blockIdx.x;
-    const float* wr = a.P + w_off + (size_t)row * ldw;
+    const __amdgpu_buffer_rsrc_t rP = st_rsrc(a.P), rS = st_rsrc(a.state);
+    const size_t wr = w_off + (size_t)row * ldw;
     const float bias = a.P[b_off + row];
     const int b0 = blockIdx.y * BT;
     const int nb = a.B - b0 < BT ? a.B - b0 : BT;              // utterances of this tile, processed concurrently
     float acc[BT];
 #pragma unroll
     for (int u = 0; u < BT; ++u) acc[u] = 0.f;
-    for (int idx = lane * 4; idx < ni; idx += 256) {
-        const float4 w = *reinterpret_cast<const float4*>(wr + idx);
+    constexpr int RV = 5;                                      // 1280 inputs per pass: every row of these nets in one pass
+    for (int i0 = 0; i0 < ni; i0 += 256 * RV) {
+        float4 wv[RV], xv[RV][BT];
 #pragma unroll
-        for (int u = 0; u < BT; ++u) {
-            if (u < nb) {
-                const float4 xv = *reinterpret_cast<const float4*>(a.state + (size_t)(b0 + u) * a.stride + x_off + idx);
-                acc[u] = fmaf(w.x, xv.x, acc[u]); acc[u] = fmaf(w.y, xv.y, acc[u]);
-                acc[u] = fmaf(w.z, xv.z, acc[u]); acc[u] = fmaf(w.w, xv.w, acc[u]);
-            }
+        for (int pc = 0; pc < RV; ++pc) {
+            const int idx = i0 + pc * 256 + lane * 4;
+            const bool ok = idx < ni;
+            wv[pc] = st_ld4(rP, ok ? (unsigned)((wr + idx) * 4) : ST_OOB);
+#pragma unroll
+            for (int u = 0; u < BT; ++u)
+                xv[pc][u] = st_ld4(rS, (ok && u < nb) ? (unsigned)(((size_t)(b0 + u) * a.stride + x_off + idx) * 4) : ST_OOB);
         }
+#pragma unroll
+        for (int pc = 0; pc < RV; ++pc)
+#pragma unroll
+            for (int u = 0; u < BT; ++u) {
+                acc[u] = fmaf(wv[pc].x, xv[pc][u].x, acc[u]); acc[u] = fmaf(wv[pc].y, xv[pc][u].y, acc[u]);
+                acc[u] = fmaf(wv[pc].z, xv[pc][u].z, acc[u]); acc[u] = fmaf(wv[pc].w, xv[pc][u].w, acc[u]);
+            }
     }
     float mine = 0.f;
 #pragma unroll
@@ -350,6 +380,7 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     const SwnGeom& g = a.g;
     const int ni = (g.K * g.Hp + 255) / 256;
     if (ni > 8 || g.seg > 16 || g.lpc > 16 || g.NO > 4096) return SWN_E_UNSUPPORTED;
+    { StArgs t; t.g = a.g; if ((size_t)plan(t) * batch * sizeof(float) >= (1ull << 31)) return SWN_E_UNSUPPORTED; }   // 32-bit buffer offsets
     swn_make_layout(&a.g, &a.y);
     plan(a);
     a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state; a.out = out; a.heads = heads;
