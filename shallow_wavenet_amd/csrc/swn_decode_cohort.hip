@@ -23,6 +23,15 @@ namespace {
 constexpr int CO = 64;          // utterances per cohort = lanes of a wave
 typedef float cf4 __attribute__((ext_vector_type(4)));
 
+// branch-free loads (see swn_decode_stepped.hip): out-of-range offset = zero, no exec-masked branch, no drained queue
+constexpr unsigned CO_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t co_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float co_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+
 struct CoArgs {
     SwnGeom g;
     SwnLayout y;
@@ -83,13 +92,25 @@ __global__ __launch_bounds__(256) void co_in_kernel(const CoArgs a, const int it
 constexpr int PW = 4;           // channel pairs per workgroup
 constexpr int KS = 16;          // input slices = waves per workgroup
 
-// stage `rows` weight rows (each `len` floats, global row stride `ld`) into LDS as wsh[row][len], all threads
+// stage `rows` weight rows (each `len` floats, global row stride `ld`) into LDS as wsh[row][len], all 1024 threads:
+// every thread issues ALL its (at most NSTG) 16-byte loads before the first LDS store
+constexpr int NSTG = 5;         // 1024 threads x 5 x 4 floats = 20 480 floats >= 8 rows x 2 304 (the longest row: K*H of H=256... = 1 792)
 __device__ __forceinline__ void stage_rows(float* wsh, const float* src, const int* rowidx, int rows, int len, int ld) {
-    const int n4 = len >> 2;
-    for (int e = threadIdx.x; e < rows * n4; e += blockDim.x) {
-        const int r = e / n4, k4 = e - r * n4;
-        *reinterpret_cast<float4*>(wsh + (size_t)r * len + 4 * k4) =
-            *reinterpret_cast<const float4*>(src + (size_t)rowidx[r] * ld + 4 * k4);
+    const __amdgpu_buffer_rsrc_t rs = co_rsrc(src);
+    const int n4 = len >> 2, tot = rows * n4;
+    float4 v[NSTG];
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+        const int e = threadIdx.x + 1024 * u;
+        const int ec = e < tot ? e : 0;
+        const int r = ec / n4, k4 = ec - r * n4;
+        v[u] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+            rs, e < tot ? (unsigned)(((size_t)rowidx[r] * ld + 4 * k4) * 4) : CO_OOB, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < NSTG; ++u) {
+        const int e = threadIdx.x + 1024 * u;
+        if (e < tot) { const int r = e / n4, k4 = e - r * n4; *reinterpret_cast<float4*>(wsh + (size_t)r * len + 4 * k4) = v[u]; }
     }
 }
 
@@ -108,6 +129,7 @@ __global__ __launch_bounds__(1024) void co_layer_kernel(const CoArgs a, const in
     const int b = c * CO + lane;
     const bool live = b < a.B;
     float* st = a.state + (size_t)c * a.stride * CO + lane;
+    const __amdgpu_buffer_rsrc_t rSt = co_rsrc(a.state + (size_t)c * a.stride * CO);      // one cohort: < 2 GiB
     const float* P = a.P;
     const int i0 = w * IPWC;
     const int dil = g.dil[l], R = a.ring_len[l];
@@ -153,9 +175,9 @@ __global__ __launch_bounds__(1024) void co_layer_kernel(const CoArgs a, const in
 #pragma unroll
             for (int tt = 0; tt < TP; ++tt) {
                 const int tap = t0 + tt;
-                const float* xr = st + (size_t)(a.ring_off[l] + pmod(q - (K - 1 - (tap < K ? tap : 0)) * dil, R) * Hp + i0) * CO;
+                const unsigned xb = (unsigned)(((size_t)(a.ring_off[l] + pmod(q - (K - 1 - (tap < K ? tap : 0)) * dil, R) * Hp + i0) * CO + lane) * 4);
 #pragma unroll
-                for (int e = 0; e < IPWC; ++e) x[tt][e] = (tap < K && i0 + e < Hp) ? xr[(size_t)e * CO] : 0.f;
+                for (int e = 0; e < IPWC; ++e) x[tt][e] = co_ld1(rSt, (tap < K && i0 + e < Hp) ? xb + (unsigned)(e * CO * 4) : CO_OOB);
             }
             if (t0 == 0 && j == 0) __syncthreads();              // the staged weights are in LDS
 #pragma unroll
@@ -208,7 +230,7 @@ __global__ __launch_bounds__(1024) void co_rowvec_kernel(const CoArgs a, size_t 
     __syncthreads();
     stage_rows(lsh, a.P + w_off, rowidx, RW, ni, ldw);
     const int ipw = ((ni + KS - 1) / KS + 3) & ~3, i0 = w * ipw, i1 = (i0 + ipw < ni) ? i0 + ipw : ni;
-    const float* xr = st + (size_t)x_off * CO;
+    const __amdgpu_buffer_rsrc_t rSt = co_rsrc(a.state + (size_t)c * a.stride * CO);
     float acc[RW];
 #pragma unroll
     for (int u = 0; u < RW; ++u) acc[u] = 0.f;
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(1024) void co_rowvec_kernel(const CoArgs a, size_t 
     for (int ib = i0; ib < i1 || first; ib += 4 * RV_X) {
         float x[4 * RV_X];
 #pragma unroll
-        for (int e = 0; e < 4 * RV_X; ++e) x[e] = (ib + e < i1) ? xr[(size_t)(ib + e) * CO] : 0.f;
+        for (int e = 0; e < 4 * RV_X; ++e) x[e] = co_ld1(rSt, (ib + e < i1) ? (unsigned)(((size_t)(x_off + ib + e) * CO + lane) * 4) : CO_OOB);
         if (first) { __syncthreads(); first = false; }
 #pragma unroll
         for (int e = 0; e < 4 * RV_X; e += 4) {
@@ -374,6 +396,11 @@ extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, con
     // slice width per wave and tap (multiple of 4); the instantiated widths cover Hp <= 256 and K <= 8
     const int ipw = ((g.Hp + KS - 1) / KS + 3) & ~3;
     if ((ipw != 4 && ipw != 12 && ipw != 16) || g.K > 8) return SWN_E_UNSUPPORTED;
+    {   // stage_rows covers rows * len <= 1024 * NSTG * 4 floats
+        const size_t cap = (size_t)1024 * NSTG * 4;
+        if ((size_t)2 * PW * g.K * g.Hp > cap || (size_t)RW * g.L * g.Hp > cap || (size_t)RW * g.Sp > cap || (size_t)RW * g.O1p > cap)
+            return SWN_E_UNSUPPORTED;
+    }
     const size_t lds_layer = ((size_t)2 * PW * g.K * g.Hp + (size_t)KS * 2 * PW * CO) * sizeof(float);
     auto lds_rv = [&](int ni) { return ((size_t)RW * ni + (size_t)KS * RW * CO) * sizeof(float); };
     const size_t lds_max = 150 * 1024;             // gfx950: 160 KB of LDS per CU, one 1024-thread workgroup each
