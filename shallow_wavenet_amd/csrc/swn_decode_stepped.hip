@@ -70,12 +70,13 @@ __device__ __forceinline__ Iter iter_of(const StArgs& a, int it) {
 // ---- input layer of iteration `it` -> ring 0 (device function: own launch in the prologue, fused into
 //      the tail of the previous step during generation)
 template <int KIND>
-__device__ __forceinline__ void input_layer(const StArgs& a, float* st, const int it, const int tid, const int nthreads) {
+__device__ __forceinline__ void input_layer(const StArgs& a, float* st, const int it, const int tid, const int nthreads,
+                                            const float* win) {
+    // win[0..WN): the sample window (LDS copy; float samples or int class indices).  All parameter loads are
+    // unconditional and selected afterwards, so the K taps cost one memory round trip, not K.
     const SwnGeom& g = a.g;
     const Iter r = iter_of(a, it);
     const float* P = a.P;
-    const float* shist = st + a.o_hist;
-    const int* ihist = reinterpret_cast<const int*>(shist);
     const int H = g.H, K = g.K, seg = g.seg, WN = a.WN;
     for (int e = tid; e < H * r.np; e += nthreads) {
         const int j = e / H, o = e - j * H, q = r.q0 + j;
@@ -83,15 +84,17 @@ __device__ __forceinline__ void input_layer(const StArgs& a, float* st, const in
         for (int k = 0; k < K; ++k) {
             const int rr = q - (K - 1 - k);
             if (KIND == SWN_KIND_LAPLACE) {
-                if (rr >= -(seg - 1)) {
-                    const int qe = r.gen ? g.rf + r.i * seg : g.rf;
-                    const float sv = r.gen ? shist[rr - qe + WN - 1] : 0.f;
-                    acc += fmaf(P[a.y.cv + (size_t)k * H + o], sv, P[a.y.cc + (size_t)k * H + o]);
-                }
-            } else if (rr >= 0) {
+                const int qe = r.gen ? g.rf + r.i * seg : g.rf;
+                int wi = rr - qe + WN - 1; wi = wi < 0 ? 0 : (wi >= WN ? WN - 1 : wi);
+                const float sv = r.gen ? win[wi] : 0.f;
+                const float t = fmaf(P[a.y.cv + (size_t)k * H + o], sv, P[a.y.cc + (size_t)k * H + o]);
+                acc += (rr >= -(seg - 1)) ? t : 0.f;
+            } else {
                 const int qe = r.gen ? g.rf + r.i : g.rf;
-                const int idx = r.gen ? ihist[rr - qe + WN - 1] : g.Q / 2;
-                acc += P[a.y.ct + ((size_t)k * g.Q + idx) * H + o];
+                int wi = rr - qe + WN - 1; wi = wi < 0 ? 0 : (wi >= WN ? WN - 1 : wi);
+                const int idx = r.gen ? __builtin_bit_cast(int, win[wi]) : g.Q / 2;
+                const float t = P[a.y.ct + ((size_t)k * g.Q + idx) * H + o];
+                acc += (rr >= 0) ? t : 0.f;
             }
         }
         st[a.ring_off[0] + pmod(q, a.ring_len[0]) * g.Hp + o] = acc / (1.f + fabsf(acc));
@@ -100,7 +103,11 @@ __device__ __forceinline__ void input_layer(const StArgs& a, float* st, const in
 
 template <int KIND>
 __global__ __launch_bounds__(256) void step_in_kernel(const StArgs a, const int it) {
-    input_layer<KIND>(a, a.state + (size_t)blockIdx.x * a.stride, it, threadIdx.x, 256);
+    __shared__ float lwin[32];
+    float* st = a.state + (size_t)blockIdx.x * a.stride;
+    if ((int)threadIdx.x < a.WN) lwin[threadIdx.x] = st[a.o_hist + threadIdx.x];
+    __syncthreads();
+    input_layer<KIND>(a, st, it, threadIdx.x, 256, lwin);
 }
 
 // ---- step_layer: ONE wave per channel pair (gate row + candidate row), weights kept in registers.
@@ -249,26 +256,36 @@ __global__ __launch_bounds__(64) void rowvec_kernel(const StArgs a, size_t w_off
 template <int KIND>
 __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const int it) {
     __shared__ float o2v[4096 + 16];
+    __shared__ float lwin[32];                 // the updated sample window, for the fused next input layer
     const SwnGeom& g = a.g;
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
     float* st = a.state + (size_t)b * a.stride;
     const int i = it - a.n_pro, seg = g.seg, WN = a.WN;
-    // out_2 rows: 8 rows per pass, 32 lanes per row
+    // out_2 rows: 8 rows per pass, 32 lanes per row; branch-free loads (a row past NO / an input past O1p reads zeros)
     {
-        const float* x = st + a.o_o1;
+        const __amdgpu_buffer_rsrc_t rP = st_rsrc(a.P), rS = st_rsrc(a.state);
+        const size_t xb = (size_t)b * a.stride + a.o_o1;
         for (int r0 = 0; r0 < g.NO; r0 += 8) {
             const int row = r0 + grp;
+            const bool rok = row < g.NO;
             float acc = 0.f;
-            if (row < g.NO) {
-                const float* wr = a.P + a.y.w2 + (size_t)row * g.O1p;
-                for (int idx = lane * 4; idx < g.O1p; idx += 128) {
-                    const float4 w = *reinterpret_cast<const float4*>(wr + idx);
-                    const float4 xv = *reinterpret_cast<const float4*>(x + idx);
-                    acc = fmaf(w.x, xv.x, acc); acc = fmaf(w.y, xv.y, acc); acc = fmaf(w.z, xv.z, acc); acc = fmaf(w.w, xv.w, acc);
+            for (int i0 = 0; i0 < g.O1p; i0 += 512) {
+                float4 wv[4], xv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int idx = i0 + u * 128 + lane * 4;
+                    const bool ok = rok && idx < g.O1p;
+                    wv[u] = st_ld4(rP, ok ? (unsigned)((a.y.w2 + (size_t)row * g.O1p + idx) * 4) : ST_OOB);
+                    xv[u] = st_ld4(rS, ok ? (unsigned)((xb + idx) * 4) : ST_OOB);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    acc = fmaf(wv[u].x, xv[u].x, acc); acc = fmaf(wv[u].y, xv[u].y, acc);
+                    acc = fmaf(wv[u].z, xv[u].z, acc); acc = fmaf(wv[u].w, xv[u].w, acc);
                 }
             }
             acc = sum32(acc);
-            if (lane == 0 && row < g.NO) o2v[row] = acc + a.P[a.y.b2 + row];
+            if (lane == 0 && rok) o2v[row] = acc + a.P[a.y.b2 + row];
         }
     }
     __syncthreads();
@@ -301,8 +318,8 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
                 for (int k = 0; k + 1 < lpc; ++k) lp[k] = lp[k + 1];
                 if (lpc > 0) lp[lpc - 1] = fd;
             }
-            for (int k = 0; k + seg < WN; ++k) shist[k] = shist[k + seg];
-            for (int j = 0; j < seg; ++j) shist[WN - seg + j] = fed[j];
+            for (int k = 0; k + seg < WN; ++k) { const float v = shist[k + seg]; shist[k] = v; lwin[k] = v; }
+            for (int j = 0; j < seg; ++j) { shist[WN - seg + j] = fed[j]; lwin[WN - seg + j] = fed[j]; }
         }
     } else if (tid < 64) {
         // softmax head, dswnv.py:361-369
@@ -331,14 +348,14 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
             const int* forced = reinterpret_cast<const int*>(a.forced);
             reinterpret_cast<int*>(a.out)[(size_t)b * a.n_steps + i] = bi;
             const int fd = forced ? forced[(size_t)b * a.n_steps + i] : bi;
-            for (int k = 0; k + 1 < WN; ++k) ihist[k] = ihist[k + 1];
-            ihist[WN - 1] = fd;
+            for (int k = 0; k + 1 < WN; ++k) { const int v = ihist[k + 1]; ihist[k] = v; lwin[k] = __builtin_bit_cast(float, v); }
+            ihist[WN - 1] = fd; lwin[WN - 1] = __builtin_bit_cast(float, fd);
         }
     }
     // the sample window was just updated through global memory by thread 0: make it visible to the
     // block (same CU), then run the next step's input layer here - one launch less per step
     __syncthreads();
-    if (i + 1 < a.n_steps) input_layer<KIND>(a, st, it + 1, tid, 256);
+    if (i + 1 < a.n_steps) input_layer<KIND>(a, st, it + 1, tid, 256, lwin);
 }
 
 // set the sample window seed (softmax: mu-law zero class) after the state was zeroed
@@ -380,7 +397,7 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     const SwnGeom& g = a.g;
     const int ni = (g.K * g.Hp + 255) / 256;
     if (ni > 8 || g.seg > 16 || g.lpc > 16 || g.NO > 4096) return SWN_E_UNSUPPORTED;
-    { StArgs t; t.g = a.g; if ((size_t)plan(t) * batch * sizeof(float) >= (1ull << 31)) return SWN_E_UNSUPPORTED; }   // 32-bit buffer offsets
+    { StArgs t; t.g = a.g; if ((size_t)plan(t) * batch * sizeof(float) >= (1ull << 31) || t.WN > 32) return SWN_E_UNSUPPORTED; }   // 32-bit buffer offsets; LDS window
     swn_make_layout(&a.g, &a.y);
     plan(a);
     a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state; a.out = out; a.heads = heads;
