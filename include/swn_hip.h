@@ -134,18 +134,21 @@ int    swn_forward(const swn_net_desc* d, const float* packed_dev, const float* 
                    const void* audio_dev, int batch, int n_frames, float* work_dev,
                    float* out_dev, float* hs_dev, void* stream);
 
-/* ---- bf16 MFMA teacher-forced stack (BL6 class: H=64, K=2, S=128, Laplace head) ----------------
- * Training-speed variant of swn_forward: bf16 weights (fragment-ordered copy made on the device by
- * swn_pack_bf16) and bf16 time-major hidden states, fp32 accumulation, fp32 gate math.
+/* ---- bf16 MFMA teacher-forced stack -------------------------------------------------------------
+ * Training-speed variant of swn_forward: bf16 weights (device copy made by swn_pack_bf16) and bf16
+ * time-major hidden states, fp32 accumulation, fp32 gate math.  Two geometry classes:
+ *   BL6 class (H=64, K=2, S=128, Laplace head): register-resident layer kernels (HBM-bound);
+ *   H a multiple of 64 up to 256, any K, Laplace or softmax (the reference's run.sh sizes): tiled GEMM stack.
  * Other geometries return SWN_E_UNSUPPORTED (use swn_forward).
  *   wbf16_dev  swn_bf16_weight_bytes() bytes, filled once per parameter set by swn_pack_bf16
- *   work_dev   swn_forward_bf16_work_bytes() bytes: hidden states [L+1][B][Tp][64] bf16
+ *   audio_dev  as for swn_forward: float waveform (Laplace) or int32 class indices (softmax)
+ *   work_dev   swn_forward_bf16_work_bytes() bytes: hidden states [L+1][B][Tp][H] bf16 (+ skip / out_1 activations)
  *   out_dev    (B, n_out, Tp) fp32 raw out_2 outputs, same meaning as swn_forward            */
 size_t swn_bf16_weight_bytes(const swn_net_desc* d);
 int    swn_pack_bf16(const swn_net_desc* d, const float* packed_dev, void* wbf16_dev, void* stream);
 size_t swn_forward_bf16_work_bytes(const swn_net_desc* d, int batch, int n_frames);
 int    swn_forward_bf16(const swn_net_desc* d, const float* packed_dev, const void* wbf16_dev,
-                        const float* cond_dev, const float* audio_dev, int batch, int n_frames,
+                        const float* cond_dev, const void* audio_dev, int batch, int n_frames,
                         void* work_dev, float* out_dev, void* stream);
 
 /* ---- Laplace output split  (cswnv_shift1.py:228-267) -----------------------------------

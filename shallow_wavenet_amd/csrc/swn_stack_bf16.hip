@@ -671,7 +671,7 @@ int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g);
 size_t swn_bf16g_weight_bytes(const SwnGeom& g);
 int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf, hipStream_t st);
 size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
-int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const float* audio,
+int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const void* audio,
                       int batch, int n_frames, void* work, float* out, hipStream_t st);
 
 extern "C" size_t swn_bf16_weight_bytes(const swn_net_desc* d) {
@@ -718,12 +718,13 @@ extern "C" size_t swn_forward_bf16_work_bytes(const swn_net_desc* d, int batch, 
 }
 
 extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, const void* wbf, const float* cond,
-                                const float* audio, int batch, int n_frames, void* work, float* out, void* stream_) {
+                                const void* audio_, int batch, int n_frames, void* work, float* out, void* stream_) {
+    const float* audio = reinterpret_cast<const float*>(audio_);      // BL6 class: Laplace, float waveform
     SwnGeom g; int rc = bf_geom(d, &g);
     if (rc == SWN_E_UNSUPPORTED && swn_bf16g_geom(d, &g) == SWN_OK) {
         if (!packed || !wbf || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
         if ((long)n_frames * g.U - 2 * g.seg + 1 < 1) return SWN_E_BADARG;
-        return swn_bf16g_forward(g, packed, wbf, cond, audio, batch, n_frames, work, out, (hipStream_t)stream_);
+        return swn_bf16g_forward(g, packed, wbf, cond, audio_, batch, n_frames, work, out, (hipStream_t)stream_);
     }
     if (rc < 0) return rc;
     if (!packed || !wbf || !cond || !audio || !work || !out || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;

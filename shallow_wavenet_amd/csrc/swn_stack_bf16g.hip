@@ -42,8 +42,9 @@ struct GemmArgs {
     float* out_f; int NO;                          // F32: out_f[(b*NO + m)*Tp + t]
     // gate
     const unsigned short* hprev; unsigned short* hnext; const float* cond;
-    size_t o_bd, o_bx, o_wup;
+    size_t o_bd, o_bx, o_wup, o_wxa;
     int H, l, seg, U, Tf, N, coff;
+    const int* aidx; int Q;                        // softmax audio_in: class index of position t, or null
 };
 
 template <int EPI>
@@ -142,6 +143,13 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
                     gz[0] = fmaf(wu, cz.x, gz[0]); gz[1] = fmaf(wu, cz.y, gz[1]); gz[2] = fmaf(wu, cz.z, gz[2]); gz[3] = fmaf(wu, cz.w, gz[3]);
                     gc[0] = fmaf(wu, cc.x, gc[0]); gc[1] = fmaf(wu, cc.y, gc[1]); gc[2] = fmaf(wu, cc.z, gc[2]); gc[3] = fmaf(wu, cc.w, gc[3]);
                 }
+                if (a.aidx) {                                 // one-hot audio input columns of in_x (dswnv.py:255-256)
+                    int idx = a.aidx[(size_t)b * a.Tp + t] % a.Q; idx = idx < 0 ? idx + a.Q : idx;
+                    const float* wa = P + a.o_wxa + ((size_t)l * a.Q + idx) * H2 + ch;
+                    const float4 az4 = *reinterpret_cast<const float4*>(wa), ac4 = *reinterpret_cast<const float4*>(wa + H);
+                    gz[0] += az4.x; gz[1] += az4.y; gz[2] += az4.z; gz[3] += az4.w;
+                    gc[0] += ac4.x; gc[1] += ac4.y; gc[2] += ac4.z; gc[3] += ac4.w;
+                }
                 const uint2 hp2 = *reinterpret_cast<const uint2*>(a.hprev + ((size_t)b * a.Tp + t) * H + ch);
                 const float hp[4] = {bf2f((unsigned short)(hp2.x & 0xffff)), bf2f((unsigned short)(hp2.x >> 16)),
                                      bf2f((unsigned short)(hp2.y & 0xffff)), bf2f((unsigned short)(hp2.y >> 16))};
@@ -208,6 +216,24 @@ __global__ __launch_bounds__(256) void bf16g_input_kernel(const float* __restric
     }
 }
 
+// softmax input layer: h0[b][t][o] = softsign(cb + sum_k ct[k][idx[t-(K-1-k)]][o]) over the taps inside the sequence (dswnv.py:257-260)
+__global__ __launch_bounds__(256) void bf16g_input_softmax_kernel(const float* __restrict__ P, size_t o_cb, size_t o_ct,
+                                                                  const int* __restrict__ audio, unsigned short* __restrict__ h0,
+                                                                  int H, int K, int Q, int Tp) {
+    const int o = threadIdx.x, b = blockIdx.y;
+    const int* au = audio + (size_t)b * Tp;
+    for (int i = 0; i < 16; ++i) {
+        const int t = blockIdx.x * 16 + i;
+        if (t >= Tp || o >= H) break;
+        float acc = P[o_cb + o];
+        for (int k = 0; k < K; ++k) {
+            const int r = t - (K - 1 - k);
+            if (r >= 0) { int idx = au[r] % Q; idx = idx < 0 ? idx + Q : idx; acc += P[o_ct + ((size_t)k * Q + idx) * H + o]; }
+        }
+        h0[((size_t)b * Tp + t) * H + o] = f2bf(acc / (1.f + fabsf(acc)));
+    }
+}
+
 struct GOff { size_t wd, wsk, w1, w2, total; };
 GOff g_offsets(const SwnGeom& g) {
     GOff o;
@@ -221,12 +247,12 @@ GOff g_offsets(const SwnGeom& g) {
 
 }  // namespace
 
-// geometry class of this file: Laplace, H a multiple of 64 (row tiles of 64 channels, k-tiles of 32), S and O1
+// geometry class of this file: Laplace or softmax, H a multiple of 64 (row tiles of 64 channels, k-tiles of 32), S and O1
 // multiples of 32, at most 256 input-layer channels per block
 int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g) {
     int rc = swn_make_geom(d, g);
     if (rc < 0) return rc;
-    if (g->kind != SWN_KIND_LAPLACE || g->H % 64 != 0 || g->H > 256 || g->S % 32 != 0 || g->O1 % 32 != 0) return SWN_E_UNSUPPORTED;
+    if (g->H % 64 != 0 || g->H > 256 || g->S % 32 != 0 || g->O1 % 32 != 0) return SWN_E_UNSUPPORTED;
     return SWN_OK;
 }
 
@@ -251,7 +277,7 @@ size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp) {
     return ((size_t)(g.L + 1) * g.H + g.S + g.O1) * batch * Tp * sizeof(unsigned short);
 }
 
-int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, const float* cond, const float* audio,
+int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, const float* cond, const void* audio,
                       int batch, int n_frames, void* work, float* out, hipStream_t st) {
     SwnLayout y; swn_make_layout(&g, &y);
     const GOff o = g_offsets(g);
@@ -264,9 +290,14 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
     // 32-bit buffer offsets: every GEMM operand must stay below 2 GiB
     if ((size_t)g.L * lstride * 2 >= (1ull << 31) || (size_t)batch * Tp * (g.S > g.O1 ? g.S : g.O1) * 2 >= (1ull << 31)) return SWN_E_UNSUPPORTED;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(bf16g_input_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
-                       audio, hs, g.H, g.K, g.seg, (int)Tp);
+    if (g.kind == SWN_KIND_LAPLACE)
+        hipLaunchKernelGGL(bf16g_input_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
+                           reinterpret_cast<const float*>(audio), hs, g.H, g.K, g.seg, (int)Tp);
+    else
+        hipLaunchKernelGGL(bf16g_input_softmax_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.ct,
+                           reinterpret_cast<const int*>(audio), hs, g.H, g.K, g.Q, (int)Tp);
     GemmArgs a = {};
+    a.aidx = (g.kind == SWN_KIND_SOFTMAX && g.audio_in) ? reinterpret_cast<const int*>(audio) : nullptr; a.Q = g.Q; a.o_wxa = y.wxa;
     a.Tp = (int)Tp; a.B = batch; a.P = packed; a.cond = cond; a.H = g.H; a.seg = g.seg; a.U = g.U; a.Tf = n_frames; a.N = g.N;
     a.coff = g.seg; a.o_bd = y.bd; a.o_bx = y.bx; a.o_wup = y.wup;
     const unsigned tx = (unsigned)((Tp + TN - 1) / TN);

@@ -159,7 +159,7 @@ class HipNet:
         return out, hs
 
     def forward_bf16(self, aux: torch.Tensor, audio: torch.Tensor, cond: Optional[torch.Tensor] = None):
-        """bf16 MFMA variant of `forward` (BL6-class Laplace nets): raw (B, n_out, Tp) fp32."""
+        """bf16 MFMA variant of `forward` (BL6-class Laplace nets and H%64==0 nets of either kind): raw (B, n_out, Tp) fp32."""
         cfg, L = self.cfg, self.lib
         d = ctypes.byref(self.desc)
         nbytes = L.swn_bf16_weight_bytes(d)
@@ -172,9 +172,10 @@ class HipNet:
             self._wbf16 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _stream_ptr(self.device)), "pack_bf16")
-        Tp = Tf * cfg.U - 2 * cfg.seg + 1
-        audio = audio.to(self.device, torch.float32).contiguous()
-        if audio.numel() != B * (Tf * cfg.U - cfg.seg):
+        soft = cfg.kind == "softmax"
+        Tp = Tf * cfg.U - 1 if soft else Tf * cfg.U - 2 * cfg.seg + 1
+        audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
+        if audio.numel() != B * (Tp if soft else Tf * cfg.U - cfg.seg):
             raise RuntimeError("audio has the wrong size")
         work = torch.empty(L.swn_forward_bf16_work_bytes(d, B, Tf), dtype=torch.uint8, device=self.device)
         out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)

@@ -66,3 +66,20 @@ def test_bf16_gemm_stack_for_large_geometries_tracks_the_fp32_kernels(gpu_ok, se
     d = (r32 - r16).abs()
     assert float(d.max()) <= 3e-3 * max(1.0, float(r32.abs().max())), float(d.max())
     assert float(d.mean()) <= 3e-4 * max(1.0, float(r32.abs().max()))
+
+
+@pytest.mark.parametrize("audio_in", [False, True])
+def test_bf16_gemm_stack_softmax_model(gpu_ok, audio_in):
+    """run.sh softmax geometry (H=256, K=7, 3x3 layers, Q=256), optionally with the one-hot audio input of in_x:
+    bf16 GEMM stack against the fp32 parity kernels (logits of magnitude ~3)."""
+    import dataclasses
+    cfg = dataclasses.replace(C.ref6_softmax(), audio_in_flag=audio_in)
+    sd = synth_state_dict(cfg, seed=5, flavor="xavier")
+    net = HipNet.from_state_dict(cfg, sd, "cuda:0")
+    B, Tf = 2, 8
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf))
+    idx = torch.randint(0, cfg.n_quantize, (B, Tf * cfg.U - 1), generator=torch.Generator().manual_seed(3))
+    r32, _ = net.forward(aux, idx)
+    r16 = net.forward_bf16(aux, idx)
+    d = (r32 - r16).abs()
+    assert float(d.max()) <= 4e-3 * max(1.0, float(r32.abs().max())), float(d.max())
