@@ -265,20 +265,34 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
 //      wup_bwd_kernel   thread = upsampler tap jj:  gwup[jj] += sum_{s,o2} dgx[o2][t] * cond[b][f][(l*seg+s)*2H+o2]
 //      with t = f*U + jj - s - coff  (the positions whose conditioning comes from frame f, tap jj)
 __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* __restrict__ dcond, float* __restrict__ gbx) {
+    // workgroup = (64 in_x rows, frame f, utterance b).  The U + seg - 1 positions the frame touches are staged
+    // through LDS with coalesced loads (lanes along t; it used to be one strided stream per thread, thrashing L1),
+    // then one thread per row does its U x seg multiply-adds out of LDS (row pitch odd: conflict-free).
+    __shared__ float tile[64][256 + 16 + 1];
+    __shared__ float wus[256];
     const SwnGeom& g = a.g;
-    const int o2 = blockIdx.x * 256 + threadIdx.x, f = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, f = blockIdx.y, b = blockIdx.z;
     const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
-    if (o2 >= H2) return;
-    const float* dg = a.dgx + ((size_t)b * H2 + o2) * a.Tp;
+    const int tbeg = f * U - (seg - 1) - a.coff, ncol = U + seg - 1;           // tile column c <-> position tbeg + c
+    wus[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
+    for (int r = w; r < 64; r += 4) {
+        const int o2 = blockIdx.x * 64 + r;
+        const float* dg = a.dgx + ((size_t)b * H2 + (o2 < H2 ? o2 : 0)) * a.Tp;
+        for (int c = lane; c < ncol; c += 64) {
+            const int t = tbeg + c;
+            tile[r][c] = (o2 < H2 && t >= 0 && t < a.Tp) ? dg[t] : 0.f;
+        }
+    }
+    __syncthreads();
+    const int o2 = blockIdx.x * 64 + tid;
+    if (tid >= 64 || o2 >= H2) return;
     float bsum = 0.f;
     for (int s = 0; s < seg; ++s) {
         float dsum = 0.f;
         for (int jj = 0; jj < U; ++jj) {
-            const int t = f * U + jj - s - a.coff;
-            if (t < 0 || t >= a.Tp) continue;
-            const float d = dg[t];
-            dsum = fmaf(a.P[a.y.wup + jj], d, dsum);
-            if (s == 0) bsum += d;                           // every position belongs to exactly one (f, jj) at s = 0
+            const float d = tile[tid][jj + (seg - 1) - s];           // t = f*U + jj - s - coff
+            dsum = fmaf(wus[jj], d, dsum);
+            if (s == 0) bsum += d;                                   // every position belongs to exactly one (f, jj) at s = 0
         }
         dcond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + s) * H2 + o2] = dsum;
     }
@@ -534,7 +548,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             launch_time(t, B, st);
         }
         if (!drop) {
-            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 255) / 256, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx);
+            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 63) / 64, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx);
             hipLaunchKernelGGL(wup_bwd_kernel, dim3(n_frames, B), dim3(256), 0, st, ga, gpacked + y.wup);
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
