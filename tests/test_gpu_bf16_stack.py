@@ -83,3 +83,23 @@ def test_bf16_gemm_stack_softmax_model(gpu_ok, audio_in):
     r16 = net.forward_bf16(aux, idx)
     d = (r32 - r16).abs()
     assert float(d.max()) <= 4e-3 * max(1.0, float(r32.abs().max())), float(d.max())
+
+
+def test_module_opt_in_bf16_forward(gpu_ok):
+    """CSWNV.bf16_forward = True routes the no-grad forward through the bf16 stack (same tuple, small differences)."""
+    from shallow_wavenet_amd.nets import cswnv_shift1 as mc
+    cfg = C.ref6_laplace(1, 4)
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=6, flavor="trained").items()})
+    m.cuda().eval()
+    aux = torch.from_numpy(synth_aux(cfg, 1, 8)).cuda()
+    audio = (torch.rand(1, 1, 8 * cfg.U - 1, generator=torch.Generator().manual_seed(2)) * 1.6 - 0.8).cuda()
+    with torch.no_grad():
+        ref = m(aux, audio)
+        m.bf16_forward = True
+        out = m(aux, audio)
+    assert len(out) == len(ref) == 4
+    for x, y in zip(out, ref):
+        assert x.shape == y.shape
+        assert float((x - y).abs().max()) <= 5e-3 * max(1.0, float(y.abs().max()))
+    assert not torch.equal(out[0], ref[0])
