@@ -64,7 +64,7 @@ def host_threads() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 20):
+def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 50):
     """time the oracle's free-running decode (reference per-step op structure) on the host cores."""
     from oracle import cpu_ref                      # checker only: never on the measured GPU path
     P = cpu_ref.as_params(sd)
