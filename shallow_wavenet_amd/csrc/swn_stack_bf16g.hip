@@ -22,7 +22,7 @@ namespace {
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
 
-constexpr int TM = 128, TN = 128, TK = 32;
+constexpr int TM = 128, TK = 32;
 constexpr int PITCH = 40;        // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
 
 __device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
@@ -47,12 +47,13 @@ struct GemmArgs {
     const int* aidx; int Q;                        // softmax audio_in: class index of position t, or null
 };
 
-template <int EPI>
+template <int EPI, int WNT>      // WNT: 16-column accumulator tiles per wave; the workgroup tile is 128 rows x 32*WNT positions
 __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
+    constexpr int TNW = 32 * WNT;
     __shared__ __attribute__((aligned(16))) unsigned short As[TM * PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned short Bs[TN * PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short Bs[TNW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int t0 = blockIdx.x * TN, m0 = blockIdx.y * TM, b = blockIdx.z;
+    const int t0 = blockIdx.x * TNW, m0 = blockIdx.y * TM, b = blockIdx.z;
     // tile row -> matrix row
     auto rowmap = [&](int tr) -> int {
         if (EPI != EPI_GATE) return m0 + tr;
@@ -67,7 +68,8 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
     const int tpos = t0 + sr;
     const int ktiles_per_blk = a.KB / TK, nk = a.nblk * ktiles_per_blk;
     constexpr int NST = 3;                      // k-tiles in flight per thread (register stages)
-    uint4 ra[NST][2], rb[NST][2];
+    constexpr int BQ = WNT / 4;                 // B rows staged per thread (128 rows per pass)
+    uint4 ra[NST][2], rb[NST][2 * BQ];
     // branch-free AND select-free: operands come through buffer resources, and everything that must read as zero
     // (a k-tile past the end of the padded k loop, a row past M, a position outside the sequence) is an
     // out-of-range offset.  Any branch around the loads - or any use of a loaded value right behind its load -
@@ -77,21 +79,24 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
     constexpr unsigned OOB = 0x80000000u;
     const unsigned a_off = aok ? (unsigned)(((size_t)arow * a.Kd + 16 * sh) * 2) : OOB;
     auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
-    auto fetch = [&](int kt, uint4 (&qa)[2], uint4 (&qb)[2]) {
+    auto fetch = [&](int kt, uint4 (&qa)[2], uint4 (&qb)[2 * BQ]) {
         const bool live = kt < nk;
         const int blk = kt / ktiles_per_blk, kin = (kt - blk * ktiles_per_blk) * TK;
         const unsigned oa = (live && aok) ? a_off + (unsigned)kt * (TK * 2) : OOB;
-        const int ts = tpos - (a.shift0 - blk * a.shift_step);
-        const bool bok = live && tpos < a.Tp && ts >= 0;
-        const unsigned ob = bok ? (unsigned)(((size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 16 * sh) * 2) : OOB;
         qa[0] = ld16(rA, oa); qa[1] = ld16(rA, oa + 16u);
-        qb[0] = ld16(rB, ob); qb[1] = ld16(rB, ob + 16u);
+#pragma unroll
+        for (int q = 0; q < BQ; ++q) {
+            const int tp = tpos + 128 * q, ts = tp - (a.shift0 - blk * a.shift_step);
+            const bool bok = live && tp < a.Tp && ts >= 0;
+            const unsigned ob = bok ? (unsigned)(((size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 16 * sh) * 2) : OOB;
+            qb[2 * q] = ld16(rB, ob); qb[2 * q + 1] = ld16(rB, ob + 16u);
+        }
     };
-    f32x4 acc[4][4];
+    f32x4 acc[4][WNT];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < WNT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NST; ++u) fetch(u, ra[u], rb[u]);
     for (int kt0 = 0; kt0 < nk; kt0 += NST) {
@@ -100,20 +105,24 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
             const int kt = kt0 + u;                          // tiles past nk are all-zero operands: no branch in the loop
             *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh) = ra[u][0];
             *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh + 8) = ra[u][1];
-            *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh) = rb[u][0];
-            *reinterpret_cast<uint4*>(Bs + sr * PITCH + 16 * sh + 8) = rb[u][1];
+#pragma unroll
+            for (int q = 0; q < BQ; ++q) {
+                *reinterpret_cast<uint4*>(Bs + (sr + 128 * q) * PITCH + 16 * sh) = rb[u][2 * q];
+                *reinterpret_cast<uint4*>(Bs + (sr + 128 * q) * PITCH + 16 * sh + 8) = rb[u][2 * q + 1];
+            }
             __syncthreads();
             fetch(kt + NST, ra[u], rb[u]);             // refill the stage just consumed: NST k-tiles of loads in flight
-            bf16x8 af[4], bfr[4];
+            bf16x8 af[4], bfr[WNT];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 4; ++i)
                 af[i] = *reinterpret_cast<const bf16x8*>(As + (64 * wm + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
-                bfr[i] = *reinterpret_cast<const bf16x8*>(Bs + (64 * wn + 16 * i + (lane & 15)) * PITCH + 8 * (lane >> 4));
-            }
+#pragma unroll
+            for (int j = 0; j < WNT; ++j)
+                bfr[j] = *reinterpret_cast<const bf16x8*>(Bs + (16 * WNT * wn + 16 * j + (lane & 15)) * PITCH + 8 * (lane >> 4));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WNT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             __syncthreads();
         }
     }
@@ -123,8 +132,8 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
         const float* P = a.P;
         const int H = a.H, H2 = 2 * a.H, l = a.l;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t0 + 64 * wn + 16 * j + n;
+        for (int j = 0; j < WNT; ++j) {
+            const int t = t0 + 16 * WNT * wn + 16 * j + n;
             if (t >= a.Tp) continue;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
@@ -166,8 +175,8 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
         }
     } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int t = t0 + 64 * wn + 16 * j + n;
+        for (int j = 0; j < WNT; ++j) {
+            const int t = t0 + 16 * WNT * wn + 16 * j + n;
             if (t >= a.Tp) continue;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -300,24 +309,25 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
     a.aidx = (g.kind == SWN_KIND_SOFTMAX && g.audio_in) ? reinterpret_cast<const int*>(audio) : nullptr; a.Q = g.Q; a.o_wxa = y.wxa;
     a.Tp = (int)Tp; a.B = batch; a.P = packed; a.cond = cond; a.H = g.H; a.seg = g.seg; a.U = g.U; a.Tf = n_frames; a.N = g.N;
     a.coff = g.seg; a.o_bd = y.bd; a.o_bx = y.bx; a.o_wup = y.wup;
-    const unsigned tx = (unsigned)((Tp + TN - 1) / TN);
+    constexpr int WNT = 4;                      // 128 x 128 workgroup tile (a 128 x 256 tile with 64 x 128 per wave needs 392 registers: one wave per SIMD, 1.4x slower)
+    const unsigned tx = (unsigned)((Tp + 32 * WNT - 1) / (32 * WNT));
     for (int l = 0; l < g.L; ++l) {
         a.A = wbf + o.wd + (size_t)l * 2 * g.H * g.K * g.H; a.M = 2 * g.H; a.Kd = g.K * g.H;
         a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K; a.src_bytes = lstride * 2;
         a.shift0 = (g.K - 1) * g.dil[l]; a.shift_step = g.dil[l];
         a.hprev = hs + (size_t)l * lstride; a.hnext = hs + (size_t)(l + 1) * lstride; a.l = l;
-        hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_GATE>, dim3(tx, g.H / 64, batch), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_GATE, WNT>), dim3(tx, g.H / 64, batch), dim3(256), 0, st, a);
     }
     // skip = relu(Wsk . [h_1 .. h_L] + b)
     a.A = wbf + o.wsk; a.M = g.S; a.Kd = g.L * g.H; a.src = hs + lstride; a.blk_stride = lstride; a.KB = g.H; a.nblk = g.L;
     a.src_bytes = (size_t)g.L * lstride * 2;
     a.shift0 = 0; a.shift_step = 0; a.bias = packed + y.bsk; a.out_bf = skipb; a.out_ld = g.S;
-    hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_RELU_BF16>, dim3(tx, (g.S + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_RELU_BF16, WNT>), dim3(tx, (g.S + TM - 1) / TM, batch), dim3(256), 0, st, a);
     a.A = wbf + o.w1; a.M = g.O1; a.Kd = g.S; a.src = skipb; a.blk_stride = 0; a.KB = g.S; a.nblk = 1; a.src_bytes = (size_t)batch * Tp * g.S * 2;
     a.bias = packed + y.b1; a.out_bf = o1b; a.out_ld = g.O1;
-    hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_RELU_BF16>, dim3(tx, (g.O1 + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_RELU_BF16, WNT>), dim3(tx, (g.O1 + TM - 1) / TM, batch), dim3(256), 0, st, a);
     a.A = wbf + o.w2; a.M = g.NO; a.Kd = g.O1; a.src = o1b; a.KB = g.O1; a.nblk = 1; a.src_bytes = (size_t)batch * Tp * g.O1 * 2;
     a.bias = packed + y.b2; a.out_f = out; a.NO = g.NO;
-    hipLaunchKernelGGL(bf16g_gemm_kernel<EPI_F32>, dim3(tx, (g.NO + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_F32, WNT>), dim3(tx, (g.NO + TM - 1) / TM, batch), dim3(256), 0, st, a);
     return swn_launch_status("swn_forward_bf16");
 }
