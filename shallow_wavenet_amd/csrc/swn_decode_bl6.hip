@@ -624,28 +624,41 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                 }
             }
         } else {
+            // this step's Exp(1) draws of wave 0 are fetched before the out_2 mat-vec: their latency hides under it
+            constexpr int Q = T::Q;
+            constexpr int QL = Q > 0 ? (Q + 63) / 64 : 1;     // classes per lane (this branch is also compiled for Laplace nets)
+            float qv[QL];
+            if (tid < 64) {
+                const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
+#pragma unroll
+                for (int k = 0; k < QL; ++k) qv[k] = tid + 64 * k < Q ? qn[tid + 64 * k] : 1.f;
+            }
             tiled_matvec<T::NO, T::O1>(w22, lds + T::o_bias + S + T::O1, lds + T::o_o1, lds + T::o_o2, false);
             lds_barrier();
             if (HEADS_ON && a.heads)
                 for (int e = tid; e < T::NO; e += NT) a.heads[((size_t)b * a.n_steps + i) * T::NO + e] = lds[T::o_o2 + e];
             if (tid < 64) {
-                // softmax head, dswnv.py:361-369
-                constexpr int Q = T::Q;
+                // softmax head, dswnv.py:361-369: p = softmax(logits); p /= sum(p); index = argmax(p / q).
+                // exp(logit - max) is evaluated once per class and kept in registers for the three passes.
                 const float* o2v = lds + T::o_o2;
-                const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
+                float lg[QL], ex[QL];
                 float m = -INFINITY;
-                for (int e = tid; e < Q; e += 64) m = fmaxf(m, o2v[e]);
+#pragma unroll
+                for (int k = 0; k < QL; ++k) { lg[k] = tid + 64 * k < Q ? o2v[tid + 64 * k] : -INFINITY; m = fmaxf(m, lg[k]); }
                 for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
                 float sum = 0.f;
-                for (int e = tid; e < Q; e += 64) sum += expf(o2v[e] - m);
+#pragma unroll
+                for (int k = 0; k < QL; ++k) { ex[k] = tid + 64 * k < Q ? expf(lg[k] - m) : 0.f; sum += ex[k]; }
                 for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
                 float sum2 = 0.f;
-                for (int e = tid; e < Q; e += 64) sum2 += expf(o2v[e] - m) / sum;
+#pragma unroll
+                for (int k = 0; k < QL; ++k) { ex[k] = ex[k] / sum; sum2 += ex[k]; }
                 for (int d = 32; d >= 1; d >>= 1) sum2 += __shfl_xor(sum2, d, 64);
                 float best = -1.f; int bi = 0x7fffffff;
-                for (int e = tid; e < Q; e += 64) {
-                    const float r = ((expf(o2v[e] - m) / sum) / sum2) / qn[e];
-                    if (r > best) { best = r; bi = e; }
+#pragma unroll
+                for (int k = 0; k < QL; ++k) {
+                    const float r = (ex[k] / sum2) / qv[k];
+                    if (tid + 64 * k < Q && r > best) { best = r; bi = tid + 64 * k; }
                 }
                 for (int d = 32; d >= 1; d >>= 1) {
                     const float ob = __shfl_xor(best, d, 64);
