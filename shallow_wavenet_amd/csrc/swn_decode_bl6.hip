@@ -72,7 +72,12 @@ struct Tr {
     static constexpr int o_w2 = o_cz + 5 * H;             // laplace: out_2 rows [NO][S] (+b2)
     static constexpr int o_bias = o_w2 + (KIND_ == SWN_KIND_LAPLACE ? NO * S_ + r4(NO) : 0);   // bsk[S], b1[O1], (softmax) b2[NO]
     static constexpr int o_wl = o_bias + S_ + O1 + (KIND_ == SWN_KIND_SOFTMAX ? NO : 0);          // [L-NREG][8][512][4]
-    static constexpr int o_end = o_wl + (L - NREG) * 8 * NT * 4;
+    // most of the out_1 matrix (input slices 0..W1L-1 of 8, lane-tiled like the global copy; as many as the 160 KB
+    // of LDS allow) stays in LDS for the single-sample Laplace net: the streamed rest's L2 latency then hides
+    // under the resident slices' FMAs
+    static constexpr int W1L = (KIND_ == SWN_KIND_LAPLACE && S_ == 128 && SEG_ <= 2) ? 4 : 0;
+    static constexpr int o_w1l = o_wl + (L - NREG) * 8 * NT * 4;
+    static constexpr int o_end = o_w1l + W1L * O1 * 16;
     static constexpr size_t lds_bytes = (size_t)o_end * sizeof(float);
 };
 
@@ -337,6 +342,7 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
         for (int e = tid; e < 2 * H; e += NT) { lds[T::o_cz + H + e] = P[a.y.cv + e]; lds[T::o_cz + 3 * H + e] = P[a.y.cc + e]; }
         for (int e = tid; e < T::NO * S; e += NT) lds[T::o_w2 + e] = P[a.y.w2 + (size_t)(e / S) * r4(S) + (e % S)];
         for (int e = tid; e < T::NO; e += NT) lds[T::o_w2 + T::NO * S + e] = P[a.y.b2 + e];
+        for (int e = tid; e < T::W1L * T::O1 * 16; e += NT) lds[T::o_w1l + e] = P[a.y.w12 + e];
     }
     // conditioning frames are copied 16 B per lane through a buffer resource (32-bit offsets)
     const __amdgpu_buffer_rsrc_t condr =
@@ -572,7 +578,32 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
             const float v = sum4(a0 + a1);
             if (hp == 0) lds[T::o_o1 + hr] = fmaxf(v + lds[T::o_bias + S + hr], 0.f);
         } else {
-            tiled_matvec<T::O1, S>(w12, lds + T::o_bias + S, lds + T::o_skip, lds + T::o_o1, true);
+            if constexpr (T::W1L > 0) {
+                // out_1, 128 x 128: the streamed slices are requested from L2 first, the resident ones come from LDS meanwhile
+                constexpr int NG = S / 16 - T::W1L;
+                const int hr = tid >> 2, hp = tid & 3;
+                float4 wg[NG];
+#pragma unroll
+                for (int mm = 0; mm < NG; ++mm) wg[mm] = buf_ld4(w12, (unsigned)(hr * 4 + hp) * 16u, (unsigned)((T::W1L + mm) * T::O1) * 64u);
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int mm = 0; mm < T::W1L; ++mm) {
+                    const float4 w0 = *reinterpret_cast<const float4*>(lds + T::o_w1l + ((mm * T::O1 + hr) * 4 + hp) * 4);
+                    const float4 x0 = *reinterpret_cast<const float4*>(lds + T::o_skip + 16 * mm + 4 * hp);
+                    float& acc = (mm & 1) ? a1 : a0;
+                    acc = fmaf(w0.x, x0.x, acc); acc = fmaf(w0.y, x0.y, acc); acc = fmaf(w0.z, x0.z, acc); acc = fmaf(w0.w, x0.w, acc);
+                }
+#pragma unroll
+                for (int mm = 0; mm < NG; ++mm) {
+                    const float4 x0 = *reinterpret_cast<const float4*>(lds + T::o_skip + 16 * (T::W1L + mm) + 4 * hp);
+                    float& acc = ((T::W1L + mm) & 1) ? a1 : a0;
+                    acc = fmaf(wg[mm].x, x0.x, acc); acc = fmaf(wg[mm].y, x0.y, acc); acc = fmaf(wg[mm].z, x0.z, acc); acc = fmaf(wg[mm].w, x0.w, acc);
+                }
+                const float v = sum4(a0 + a1);
+                if (hp == 0) lds[T::o_o1 + hr] = fmaxf(v + lds[T::o_bias + S + hr], 0.f);
+            } else {
+                tiled_matvec<T::O1, S>(w12, lds + T::o_bias + S, lds + T::o_skip, lds + T::o_o1, true);
+            }
         }
         lds_barrier(); STAMP(8)
 
