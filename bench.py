@@ -87,6 +87,34 @@ def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 50):
             "sample": f"cfg2 B=1 Tf={frames} ({n} generated samples) free-running oracle decode"}
 
 
+def stack_leg(cfg: C.NetConfig, net: HipNet, dev, batch: int = 64, frames: int = 150, reps: int = 10):
+    """teacher-forced bf16 stack (cfg4 family, the home of the fused residual-block kernel) priced against the
+    HBM roof: algorithmic bytes per position = h0 write 2H + L x (read h, write h') 4H + head reads 2LH +
+    raw output 4*n_out + audio 4, conditioning 4*2H*L/U; HIP events on the launch stream."""
+    T = frames * cfg.U
+    aux = torch.from_numpy(synth_aux(cfg, batch, frames, seed=7)).to(dev)
+    audio = (torch.rand(batch, T - cfg.seg, device=dev) * 2 - 1) * 0.5
+    cond = net.frontend(aux)
+    for _ in range(2):
+        net.forward_bf16(aux, audio, cond=cond)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        net.forward_bf16(aux, audio, cond=cond)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    H, L = cfg.H, cfg.L
+    bpp = 2 * H + L * 4 * H + 2 * L * H + 4 * cfg.n_out + 4 + 4 * 2 * H * L / cfg.U
+    pos = batch * T
+    ach = bpp * pos / (ms * 1e-3) / 1e9
+    return {"workload": f"teacher-forced bf16 forward, BL6, {batch} x {T} positions (input + {L} fused residual blocks + head)",
+            "ms": round(ms, 4), "positions_per_s": round(pos / (ms * 1e-3), 1), "bound": "hbm",
+            "algorithmic_bytes_per_position": round(bpp, 1), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+            "note": "per-kernel split: profiles/r01_forward_b64_kernel_stats.csv (bf16_layer_units_kernel 46 % of the roof)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -165,6 +193,7 @@ def main():
                      "note": "latency-bound sequential chain; working set is L2/LDS/VGPR resident (SURVEY 7.3)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["stack"] = stack_leg(cfg, net, dev)
         line["cpu_baseline"] = cpu_baseline(cfg, sd)
     if rank == 0:
         print(json.dumps(line), flush=True)
