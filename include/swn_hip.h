@@ -197,6 +197,15 @@ int    swn_backward_drop(const swn_net_desc* d, const float* packed_dev, const f
                          const void* audio_dev, const float* fwd_work_dev, const float* hs_dev,
                          const float* drop_x_dev, const float* const* drop_h_host, const float* grad_out_dev,
                          int batch, int n_frames, float* work_dev, float* gpacked_dev, void* stream);
+/* ---- arithmetic of the backward contractions (process-wide switch) -------------------------------------------
+ * mode 0 (default): fp32 operands on the matrix cores, bit-compatible with an fmaf chain - the parity mode the
+ *                   gradient fixtures are checked in.
+ * mode 1: mixed precision - the same fp32 tensors in HBM, operands rounded to bf16 on their way into LDS,
+ *         v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what torch.autocast(bfloat16) would do to the
+ *         reference's conv backward); gradients agree with mode 0 to ~1e-2 relative per tensor.
+ * Applies to swn_backward, swn_backward_drop and the sample-rate in_x GEMM of swn_forward_drop. */
+int    swn_train_set_precision(int mode);
+int    swn_train_get_precision(void);
 /* gradient of swn_laplace_head: grads wrt mu / b / logb / a (time-major, any may be NULL) -> grad wrt raw */
 int    swn_laplace_head_backward(const swn_net_desc* d, const float* out_dev, int batch, int tp,
                                  const float* gmu_dev, const float* gb_dev, const float* glogb_dev,

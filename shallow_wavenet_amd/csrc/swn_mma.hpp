@@ -29,3 +29,24 @@ __device__ __forceinline__ void swn_mma_64x64x16(const float (*As)[SWN_MMA_PITCH
 // row / column of accumulator element (mt, i) inside the 64x64 tile
 __device__ __forceinline__ int swn_mma_row(int lane, int mt, int i) { return 16 * mt + 4 * (lane >> 4) + i; }
 __device__ __forceinline__ int swn_mma_col(int lane, int w) { return 16 * w + (lane & 15); }
+
+// ---- bf16-operand variant (mixed-precision training mode, swn_train_set_precision(1)): the same 64 x 64 tile and
+// accumulator layout, k-tile of 32 with v_mfma_f32_16x16x32_bf16 (16x the rate of the exact fp32 instruction), fp32
+// accumulation.  LDS holds the operands row-major in k as packed bf16 pairs: As[row][k/2], Bs[col][k/2], 80-byte rows
+// (conflict-free 16-byte fragment reads).
+#define SWN_MMB_PITCH 20
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 swn_bf16x8;
+
+__device__ __forceinline__ unsigned swn_pack_bf16(float lo, float hi) {
+    return (unsigned)__builtin_bit_cast(unsigned short, (__bf16)lo) | ((unsigned)__builtin_bit_cast(unsigned short, (__bf16)hi) << 16);
+}
+__device__ __forceinline__ void swn_mmb_64x64x32(const unsigned (*As)[SWN_MMB_PITCH], const unsigned (*Bs)[SWN_MMB_PITCH],
+                                                 swn_f32x4 (&acc)[4], const int lane, const int w) {
+    const int kq = lane >> 4, rc = lane & 15;
+    const swn_bf16x8 b = *reinterpret_cast<const swn_bf16x8*>(&Bs[16 * w + rc][4 * kq]);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const swn_bf16x8 a = *reinterpret_cast<const swn_bf16x8*>(&As[16 * mt + rc][4 * kq]);
+        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
+    }
+}

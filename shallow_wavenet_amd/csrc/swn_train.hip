@@ -12,6 +12,7 @@
 // the Laplace head.  Hidden states h_0..h_L saved by the forward are reused; the gate pre-activations
 // are recomputed (one extra conv GEMM per layer) instead of being stored.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include "swn_geom.hpp"
 #include "swn_mma.hpp"
 
@@ -116,6 +117,87 @@ __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
         }
 }
 
+// bf16-operand twin of time_gemm_kernel (swn_train_set_precision(1)): same operands in HBM (fp32), rounded to bf16 on
+// their way into LDS, k-tiles of 32, fp32 accumulators and the same epilogue.  A thread stages k-PAIRS (one packed
+// LDS word each); the (tap, c) of every k index advances without divisions.
+template <bool XMUL>
+__global__ __launch_bounds__(256) void time_gemm_bf16_kernel(const TimeGemm g) {
+    __shared__ __attribute__((aligned(16))) unsigned As[64][SWN_MMB_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned Bs[64][SWN_MMB_PITCH];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const __amdgpu_buffer_rsrc_t rA = rsrc_of(g.A), rX = rsrc_of(g.X + (size_t)b * g.x_sb);
+    const __amdgpu_buffer_rsrc_t rM = rsrc_of(XMUL ? g.xmul + (size_t)b * g.xm_sb : g.A);
+    const int Kd = g.taps * g.KC;
+    swn_f32x4 acc[4] = {};
+    const int kp = tid & 15, tt = tid & 63, kq = tid >> 6;
+    const int dtap = 32 / g.KC, dc = 32 - dtap * g.KC;          // a k-tile step in (tap, c) coordinates
+    int tapA[2], cA[2], tapB[4][2], cB[4][2];
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+        const int kk = 2 * kp + e; tapA[e] = kk / g.KC; cA[e] = kk - tapA[e] * g.KC;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int kb = 2 * (kq + 4 * i) + e; tapB[i][e] = kb / g.KC; cB[i][e] = kb - tapB[i][e] * g.KC; }
+    }
+    unsigned arow[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { const int m = m0 + (tid >> 4) + 16 * i; arow[i] = m < g.M ? (unsigned)(m * g.a_sm * 4) : SWN_OOB; }
+    const int XT = g.XT ? g.XT : g.T;
+    const bool tok = t0 + tt < g.T;
+    constexpr int NST = 3;
+    float ra[NST][8], rb[NST][8], rm[NST][8];
+    auto fetch = [&](int k0, float (&qa)[8], float (&qb)[8], float (&qm)[8]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const bool ka = k0 + 2 * kp + e < Kd;
+            const unsigned ko = (unsigned)((tapA[e] * g.a_stap + cA[e] * g.a_sc) * 4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) qa[2 * i + e] = bld1(rA, (ka && arow[i] != SWN_OOB) ? arow[i] + ko : SWN_OOB);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ts = t0 + tt + g.sgn * (tapB[i][e] - g.center) * g.dil;
+                const bool ok = k0 + 2 * (kq + 4 * i) + e < Kd && ts >= 0 && ts < XT && tok;
+                qb[2 * i + e] = bld1(rX, ok ? (unsigned)((cB[i][e] * g.x_sc + ts * g.x_st) * 4) : SWN_OOB);
+                if (XMUL) qm[2 * i + e] = bld1(rM, ok ? (unsigned)(((size_t)cB[i][e] * g.xm_sc + ts) * 4) : SWN_OOB);
+            }
+            tapA[e] += dtap; cA[e] += dc; if (cA[e] >= g.KC) { cA[e] -= g.KC; ++tapA[e]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { tapB[i][e] += dtap; cB[i][e] += dc; if (cB[i][e] >= g.KC) { cB[i][e] -= g.KC; ++tapB[i][e]; } }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NST; ++u) fetch(32 * u, ra[u], rb[u], rm[u]);
+    for (int k0 = 0; k0 < Kd; k0 += 32 * NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {                 // tiles past Kd hold zeros: no branch inside the loop
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                As[(tid >> 4) + 16 * i][kp] = swn_pack_bf16(ra[u][2 * i], ra[u][2 * i + 1]);
+                Bs[tt][kq + 4 * i] = XMUL ? swn_pack_bf16(rb[u][2 * i] * rm[u][2 * i], rb[u][2 * i + 1] * rm[u][2 * i + 1])
+                                          : swn_pack_bf16(rb[u][2 * i], rb[u][2 * i + 1]);
+            }
+            __syncthreads();
+            fetch(k0 + 32 * (u + NST), ra[u], rb[u], rm[u]);
+            swn_mmb_64x64x32(As, Bs, acc, lane, w);
+            __syncthreads();
+        }
+    }
+    const int t = t0 + swn_mma_col(lane, w);
+    if (t >= g.T) return;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + swn_mma_row(lane, mt, i);
+            if (m >= g.M) continue;
+            float v = acc[mt][i];
+            if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
+            if (g.ymul) v *= g.ymul[(size_t)b * g.ym_sb + (size_t)m * g.ym_sm + t];
+            float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
+            *y = g.accumulate ? *y + v : v;
+        }
+}
+
 struct ReduceGemm {
     const float* P; long p_sb, p_sm, p_st;          // P[b][m][t]
     const float* Q; long q_sb, q_sc, q_st;          // Q[b][c][t]
@@ -183,6 +265,87 @@ __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
             v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
             const int m = m0 + (tid >> 4) + 16 * i;
             if ((tid & 15) == 0 && m < g.M) atomicAdd(g.gb + m, v);
+        }
+    }
+    const int nc = n0 + swn_mma_col(lane, w);
+    if (nc >= Nc) return;
+    const int tap = nc / g.KC, c = nc - tap * g.KC;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + swn_mma_row(lane, mt, i);
+            if (m < g.M) atomicAdd(g.G + m * g.g_sm + tap * g.g_stap + c * g.g_sc, acc[mt][i]);
+        }
+}
+
+// bf16-operand twin of reduce_gemm_kernel: time tiles of 32, operands fetched through buffer resources two tiles
+// ahead (no branch around a load), rounded to bf16 into LDS; row sums for the bias gradient stay exact fp32.
+template <bool QMUL>
+__global__ __launch_bounds__(256) void reduce_gemm_bf16_kernel(const ReduceGemm g) {
+    __shared__ __attribute__((aligned(16))) unsigned Ps[64][SWN_MMB_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned Qs[64][SWN_MMB_PITCH];
+    const int nseg = (g.T + g.TS - 1) / g.TS;
+    const int b = blockIdx.z / nseg, ts0 = (blockIdx.z - b * nseg) * g.TS;
+    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int Nc = g.taps * g.KC;
+    const __amdgpu_buffer_rsrc_t rP = rsrc_of(g.P + (size_t)b * g.p_sb), rQ = rsrc_of(g.Q + (size_t)b * g.q_sb);
+    const __amdgpu_buffer_rsrc_t rM = rsrc_of(QMUL ? g.qmul + (size_t)b * g.qm_sb : g.P);
+    swn_f32x4 acc[4] = {};
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tend = ts0 + g.TS < g.T ? ts0 + g.TS : g.T;
+    const int QT = g.QT ? g.QT : g.T;
+    const int kp = tid & 15;                    // time pair (2kp, 2kp+1) of the tile; rows / columns (tid >> 4) + 16 i
+    int qc[4], qshift[4]; bool qok[4], mok[4]; int pm[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int nc = n0 + (tid >> 4) + 16 * i;
+        const int tap = nc / g.KC;
+        qok[i] = nc < Nc; qc[i] = nc - tap * g.KC; qshift[i] = g.sgn * (tap - g.center) * g.dil;
+        pm[i] = m0 + (tid >> 4) + 16 * i; mok[i] = pm[i] < g.M;
+    }
+    constexpr int NST = 2;
+    float rp[NST][8], rq[NST][8], rm[NST][8];
+    auto fetch = [&](int t0, float (&qp)[8], float (&qq)[8], float (&qm)[8]) {
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int t = t0 + 2 * kp + e;
+            const bool okt = t < tend;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                qp[2 * i + e] = bld1(rP, (okt && mok[i]) ? (unsigned)((pm[i] * g.p_sm + t * g.p_st) * 4) : SWN_OOB);
+                const int tsrc = t + qshift[i];
+                const bool ok = okt && qok[i] && tsrc >= 0 && tsrc < QT;
+                qq[2 * i + e] = bld1(rQ, ok ? (unsigned)((qc[i] * g.q_sc + tsrc * g.q_st) * 4) : SWN_OOB);
+                if (QMUL) qm[2 * i + e] = bld1(rM, ok ? (unsigned)(((size_t)qc[i] * g.qm_sc + tsrc) * 4) : SWN_OOB);
+            }
+        }
+    };
+#pragma unroll
+    for (int u = 0; u < NST; ++u) fetch(ts0 + 32 * u, rp[u], rq[u], rm[u]);
+    for (int t0 = ts0; t0 < tend; t0 += 32 * NST) {
+#pragma unroll
+        for (int u = 0; u < NST; ++u) {                 // tiles past tend hold zeros
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                rs[i] += rp[u][2 * i] + rp[u][2 * i + 1];
+                Ps[(tid >> 4) + 16 * i][kp] = swn_pack_bf16(rp[u][2 * i], rp[u][2 * i + 1]);
+                Qs[(tid >> 4) + 16 * i][kp] = QMUL ? swn_pack_bf16(rq[u][2 * i] * rm[u][2 * i], rq[u][2 * i + 1] * rm[u][2 * i + 1])
+                                                    : swn_pack_bf16(rq[u][2 * i], rq[u][2 * i + 1]);
+            }
+            __syncthreads();
+            fetch(t0 + 32 * (u + NST), rp[u], rq[u], rm[u]);
+            swn_mmb_64x64x32(Ps, Qs, acc, lane, w);
+            __syncthreads();
+        }
+    }
+    if (g.gb && blockIdx.y == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            if (kp == 0 && mok[i]) atomicAdd(g.gb + pm[i], v);
         }
     }
     const int nc = n0 + swn_mma_col(lane, w);
@@ -377,17 +540,39 @@ __global__ __launch_bounds__(256) void laplace_head_bwd_kernel(const float* __re
 
 size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
+// process-wide arithmetic mode of the two contraction kernels (swn_train_set_precision)
+std::atomic<int> g_train_bf16{0};
+
 void launch_time(const TimeGemm& g, int B, hipStream_t st) {
-    if (g.xmul) { hipLaunchKernelGGL(time_gemm_kernel<true>, dim3((g.T + 63) / 64, (g.M + 63) / 64, B), dim3(256), 0, st, g); return; }
-    hipLaunchKernelGGL(time_gemm_kernel<false>, dim3((g.T + 63) / 64, (g.M + 63) / 64, B), dim3(256), 0, st, g);
+    const dim3 grid((g.T + 63) / 64, (g.M + 63) / 64, B);
+    if (g_train_bf16.load(std::memory_order_relaxed)) {
+        if (g.xmul) hipLaunchKernelGGL(time_gemm_bf16_kernel<true>, grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(time_gemm_bf16_kernel<false>, grid, dim3(256), 0, st, g);
+        return;
+    }
+    if (g.xmul) { hipLaunchKernelGGL(time_gemm_kernel<true>, grid, dim3(256), 0, st, g); return; }
+    hipLaunchKernelGGL(time_gemm_kernel<false>, grid, dim3(256), 0, st, g);
 }
 void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
     g.TS = 512;
     const int nseg = (g.T + g.TS - 1) / g.TS;
-    hipLaunchKernelGGL(reduce_gemm_kernel, dim3((g.M + 63) / 64, (g.taps * g.KC + 63) / 64, B * nseg), dim3(256), 0, st, g);
+    const dim3 grid((g.M + 63) / 64, (g.taps * g.KC + 63) / 64, B * nseg);
+    if (g_train_bf16.load(std::memory_order_relaxed)) {
+        if (g.qmul) hipLaunchKernelGGL(reduce_gemm_bf16_kernel<true>, grid, dim3(256), 0, st, g);
+        else hipLaunchKernelGGL(reduce_gemm_bf16_kernel<false>, grid, dim3(256), 0, st, g);
+        return;
+    }
+    hipLaunchKernelGGL(reduce_gemm_kernel, grid, dim3(256), 0, st, g);
 }
 
 }  // namespace
+
+extern "C" int swn_train_set_precision(int mode) {
+    if (mode != 0 && mode != 1) return SWN_E_BADARG;
+    g_train_bf16.store(mode, std::memory_order_relaxed);
+    return SWN_OK;
+}
+extern "C" int swn_train_get_precision(void) { return g_train_bf16.load(std::memory_order_relaxed); }
 
 extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int n_frames) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;

@@ -56,6 +56,27 @@ LAYOUT_FIELDS = ("scale_w", "scale_b", "aux_w0", "aux_w1", "aux_w2", "aux_w3", "
                  "b2", "total", "bxr")
 
 
+class train_precision:
+    """context manager / setter for the arithmetic of the backward contractions (include/swn_hip.h,
+    swn_train_set_precision): "fp32" = exact fp32 MFMA (parity mode, default), "bf16" = bf16 operands with fp32
+    accumulation.  Process-wide, like torch.backends flags."""
+    MODES = {"fp32": 0, "bf16": 1}
+
+    def __init__(self, mode: str):
+        if mode not in self.MODES:
+            raise ValueError(f"train precision must be one of {sorted(self.MODES)}")
+        L = _lib.lib()
+        self._prev = int(L.swn_train_get_precision())
+        _lib.check(L.swn_train_set_precision(self.MODES[mode]), "train_set_precision")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        _lib.check(_lib.lib().swn_train_set_precision(self._prev), "train_set_precision")
+        return False
+
+
 def layout_offsets(cfg: NetConfig) -> Dict[str, int]:
     """float offsets of the packed sections (swn_layout_offsets)."""
     d = _lib.desc_from_cfg(cfg)

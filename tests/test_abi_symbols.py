@@ -42,6 +42,15 @@ def test_geometry_agrees_with_host_config(cfg):
     assert lib.swn_packed_floats(ctypes.byref(d)) > cfg.n_params() * 0.9
 
 
+def test_train_precision_switch_is_host_state():
+    """no GPU call behind it: include/swn_hip.h swn_train_set_precision / swn_train_get_precision"""
+    lib = _lib.lib()
+    assert lib.swn_train_get_precision() == 0
+    assert lib.swn_train_set_precision(1) == 0 and lib.swn_train_get_precision() == 1
+    assert lib.swn_train_set_precision(2) < 0 and lib.swn_train_get_precision() == 1
+    assert lib.swn_train_set_precision(0) == 0 and lib.swn_train_get_precision() == 0
+
+
 def test_bad_descriptors_are_rejected():
     lib = _lib.lib()
     d = _lib.desc_from_cfg(C.bl6_laplace())

@@ -1,0 +1,112 @@
+"""GPU: mixed-precision mode of the backward contractions (swn_train_set_precision(1): bf16 operands, fp32
+accumulation) against the exact-fp32 mode of the same kernels and against the reference's own gradients.
+
+Tolerance (bf16 has 8 mantissa bits; products are summed in fp32): per parameter tensor
+||g_bf16 - g_ref||_2 <= 2e-2 * ||g_ref||_2 + 1e-6, and the loss itself is untouched (the forward stays fp32)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import golden_names, load_golden
+from shallow_wavenet_amd import config as C
+from shallow_wavenet_amd.nets import cswnv_shift1 as mc
+from shallow_wavenet_amd.nets import dswnv as md
+from shallow_wavenet_amd.runtime import train_precision
+from shallow_wavenet_amd.synth import synth_aux, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_")) and "loss" in load_golden(n)[1]]
+SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_")) and "loss" in load_golden(n)[1]]
+
+
+def _grads(model):
+    return {k: p.grad.detach().double().cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def _close(name, got, ref, tol=2e-2):
+    for k, r in ref.items():
+        err = np.linalg.norm((got[k] - r).ravel())
+        assert err <= tol * np.linalg.norm(r.ravel()) + 1e-6, (name, k, err, np.linalg.norm(r.ravel()))
+
+
+def test_precision_switch_round_trips(gpu_ok):
+    from shallow_wavenet_amd import _lib
+    L = _lib.lib()
+    assert L.swn_train_get_precision() == 0
+    with train_precision("bf16"):
+        assert L.swn_train_get_precision() == 1
+    assert L.swn_train_get_precision() == 0
+    assert L.swn_train_set_precision(7) < 0
+    with pytest.raises(ValueError):
+        train_precision("fp8")
+
+
+@pytest.mark.parametrize("name", LAP)
+def test_laplace_gradients_bf16_mode(gpu_ok, name):
+    cfg, d = load_golden(name)
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=int(d["wseed"]), flavor=str(d["flavor"])).items()})
+    m.cuda().train()
+    tgt = torch.from_numpy(d["loss_target"]).cuda()
+    out = {}
+    for mode in ("fp32", "bf16"):
+        for p in m.parameters():
+            p.grad = None
+        with train_precision(mode):
+            res = m(torch.from_numpy(d["aux"]).cuda(), torch.from_numpy(d["fwd_audio"]).cuda(), do=False, clip=False)
+            loss = mc.LaplaceLoss()(res[0], res[1], tgt, log_b=res[2], log=False)
+            if cfg.lpc > 0:
+                loss = loss + 0.1 * res[3].pow(2).mean()
+            assert abs(loss.item() - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+            loss.backward()
+        out[mode] = _grads(m)
+    _close(name, out["bf16"], out["fp32"])
+    ref = {k: d[f"grad_{k}"].astype(np.float64) for k in out["fp32"] if f"grad_{k}" in d}
+    _close(name, out["bf16"], ref)
+    assert any(np.abs(out["bf16"][k] - out["fp32"][k]).max() > 0 for k in out["fp32"]), "bf16 mode did not engage"
+
+
+@pytest.mark.parametrize("name", SMX[:2])
+def test_softmax_gradients_bf16_mode(gpu_ok, name):
+    cfg, d = load_golden(name)
+    m = md.DSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=int(d["wseed"]), flavor=str(d["flavor"])).items()})
+    m.cuda().train()
+    idx = torch.from_numpy(d["fwd_audio_idx"]).cuda()
+    tgt = torch.from_numpy(d["loss_target"]).cuda()
+    out = {}
+    for mode in ("fp32", "bf16"):
+        for p in m.parameters():
+            p.grad = None
+        with train_precision(mode):
+            logits = m(md.OneHot(idx, cfg.n_quantize).transpose(1, 2), torch.from_numpy(d["aux"]).cuda())
+            loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tgt.reshape(-1))
+            loss.backward()
+        out[mode] = _grads(m)
+    _close(name, out["bf16"], out["fp32"])
+
+
+@pytest.mark.parametrize("shape", ["bl6", "ref6"])
+def test_full_size_gradients_bf16_mode(gpu_ok, shape):
+    """BASELINE cfg4-like chunk (4 x 20 frames) at the full BL6 / run.sh geometries: ragged tiles, K=7 taps."""
+    cfg = C.bl6_laplace(1, 0) if shape == "bl6" else C.ref6_laplace(1, 4)
+    B, Tf = 3, 12
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True).items()})
+    m.cuda().train()
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    T = Tf * cfg.U
+    audio = (torch.rand(B, 1, T - cfg.seg, generator=torch.Generator().manual_seed(2)) * 1.8 - 0.9).cuda()
+    Tp = T - 2 * cfg.seg + 1
+    tgt = (torch.rand(B, Tp, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9).cuda()
+    out = {}
+    for mode in ("fp32", "bf16"):
+        for p in m.parameters():
+            p.grad = None
+        with train_precision(mode):
+            res = m(aux, audio)
+            loss = mc.LaplaceLoss()(res[0].reshape(B, Tp), res[1].reshape(B, Tp), tgt, log_b=res[2].reshape(B, Tp), log=False)
+            loss.backward()
+        out[mode] = _grads(m)
+    _close(shape, out["bf16"], out["fp32"])

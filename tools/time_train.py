@@ -1,4 +1,5 @@
-"""dev tool: one training step (forward + backward, fp32 HIP kernels) at the BASELINE cfg4 shape."""
+"""dev tool: one training step (forward + backward HIP kernels) at the BASELINE cfg4 shape.
+  python tools/time_train.py [B Tf [fp32|bf16]]   (third argument: arithmetic of the backward contractions)"""
 import sys, os
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R)
 import torch
@@ -7,6 +8,9 @@ from shallow_wavenet_amd.nets import cswnv_shift1 as mc
 from shallow_wavenet_amd.synth import synth_state_dict, synth_aux
 
 B, Tf = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8, 150)
+from shallow_wavenet_amd.runtime import train_precision
+MODE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
+train_precision(MODE)
 for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     m = mc.CSWNV(**cfg.ctor_kwargs())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True).items()})
@@ -35,4 +39,4 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     macs_fwd = (cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.S * cfg.S + cfg.n_out * cfg.S) * B * Tp
-    print(f"{nm} B={B} Tf={Tf}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
+    print(f"{nm} B={B} Tf={Tf} [{MODE}]: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
