@@ -282,6 +282,57 @@ int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf_, hipStream_
     return swn_launch_status("swn_pack_bf16");
 }
 
+// ---- bf16 time-major [.][t][C] -> fp32 channel-major [.][C][Tp] (what the fp32 backward reads), 64 x 64 tiles through
+// LDS: 16-byte loads along c, 256-byte rows stored along t.  z = matrix index: src z*src_stride, dst (z % nb)*dst_bs + (z / nb)*dst_ls
+__global__ __launch_bounds__(256) void bf16g_expand_kernel(const unsigned short* __restrict__ src, size_t src_stride, int C, int Tp,
+                                                           float* __restrict__ dst, int nb, size_t dst_bs, size_t dst_ls) {
+    __shared__ float tile[64][65];
+    const int z = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+    const unsigned short* S = src + (size_t)z * src_stride;
+    float* D = dst + (size_t)(z % nb) * dst_bs + (size_t)(z / nb) * dst_ls;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int e = tid + 256 * i, t = e >> 3, cq = (e & 7) * 8;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (t0 + t < Tp && c0 + cq < C) v = *reinterpret_cast<const uint4*>(S + (size_t)(t0 + t) * C + c0 + cq);     // C % 8 == 0
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            tile[cq + 2 * j][t] = __uint_as_float(u[j] << 16);
+            tile[cq + 2 * j + 1][t] = __uint_as_float(u[j] & 0xffff0000u);
+        }
+    }
+    __syncthreads();
+    const int t = tid & 63;
+    if (t0 + t >= Tp) return;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = (tid >> 6) + 4 * i;
+        if (c0 + c < C) D[(size_t)(c0 + c) * Tp + t0 + t] = tile[c][t];
+    }
+}
+
+// what swn_bf16g_forward left in `work` -> the fp32 work layout of swn_forward: hs | relu(skip) | relu(out_1)
+int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, hipStream_t st) {
+    auto r64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const unsigned short* hs = reinterpret_cast<const unsigned short*>(work);
+    const size_t lstride = (size_t)batch * Tp * g.H;
+    const unsigned short* skipb = hs + (size_t)(g.L + 1) * lstride;
+    const unsigned short* o1b = skipb + (size_t)batch * Tp * g.S;
+    float* s1 = fwd_work + r64((size_t)batch * (g.L + 1) * g.H * Tp);
+    float* r1 = s1 + r64((size_t)batch * g.S * Tp);
+    const unsigned tx = (unsigned)((Tp + 63) / 64);
+    (void)hipGetLastError();
+    // hidden states: matrix z = l * B + b  ->  dst [b][l][H][Tp]
+    hipLaunchKernelGGL(bf16g_expand_kernel, dim3(tx, (g.H + 63) / 64, (g.L + 1) * batch), dim3(256), 0, st,
+                       hs, (size_t)Tp * g.H, g.H, (int)Tp, fwd_work, batch, (size_t)(g.L + 1) * g.H * Tp, (size_t)g.H * Tp);
+    hipLaunchKernelGGL(bf16g_expand_kernel, dim3(tx, (g.S + 63) / 64, batch), dim3(256), 0, st,
+                       skipb, (size_t)Tp * g.S, g.S, (int)Tp, s1, batch, (size_t)g.S * Tp, (size_t)0);
+    hipLaunchKernelGGL(bf16g_expand_kernel, dim3(tx, (g.O1 + 63) / 64, batch), dim3(256), 0, st,
+                       o1b, (size_t)Tp * g.O1, g.O1, (int)Tp, r1, batch, (size_t)g.O1 * Tp, (size_t)0);
+    return swn_launch_status("swn_bf16_work_to_f32");
+}
+
 size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp) {
     return ((size_t)(g.L + 1) * g.H + g.S + g.O1) * batch * Tp * sizeof(unsigned short);
 }

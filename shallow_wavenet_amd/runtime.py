@@ -239,11 +239,37 @@ class HipNet:
         audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
         d = ctypes.byref(self.desc)
         work = torch.empty(self.lib.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        out = self._bf16_train_forward(cond, audio, B, Tf, work) if self.lib.swn_train_get_precision() == 1 else None
+        if out is not None:
+            return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
         out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             _lib.check(self.lib.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
                                             _ptr(out), _ptr(None), _stream_ptr(self.device)), "forward")
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
+
+    def _bf16_train_forward(self, cond, audio, B, Tf, work):
+        """mixed-precision mode, GEMM-stack geometries: bf16 forward, then its bf16 activations expanded into the fp32
+        buffers swn_backward reads.  Returns None (caller runs the fp32 forward) where the library has no such path.
+        The bf16 copy of the weights is refreshed on every call: the parameters move between training steps."""
+        L = self.lib
+        d = ctypes.byref(self.desc)
+        if L.swn_bf16_train_forward_supported(d) != 1:
+            return None
+        nbytes = L.swn_bf16_weight_bytes(d)
+        wb = torch.empty(L.swn_forward_bf16_work_bytes(d, B, Tf), dtype=torch.uint8, device=self.device)
+        if getattr(self, "_wbf16", None) is None:
+            self._wbf16 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        soft = self.cfg.kind == "softmax"
+        Tp = Tf * self.cfg.U - 1 if soft else Tf * self.cfg.U - 2 * self.cfg.seg + 1
+        out = torch.empty((B, self.cfg.n_out, Tp), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            st = _stream_ptr(self.device)
+            _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), st), "pack_bf16")
+            _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
+                                          _ptr(wb), _ptr(out), st), "forward_bf16")
+            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(wb), B, Tf, _ptr(work), st), "bf16_work_to_f32")
+        return out
 
     def _drop_args(self, drop):
         drop_x, drop_h = drop
