@@ -48,6 +48,44 @@ __device__ __forceinline__ swn_fl4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) 
     return __builtin_bit_cast(swn_fl4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
 }
 
+// Epilogue of the time contractions: relu mask, dropout multiplier, accumulate, store - for NV results of one thread.
+// The reads of one kind are issued together through a buffer resource (invalid rows = the out-of-range offset) BEFORE
+// anything is stored: written as a per-element read-modify-write the compiler must keep every load behind the previous
+// store (Y may alias), i.e. one global round trip per element.
+template <int NV>
+__device__ __forceinline__ void tg_epilogue(const TimeGemm& g, const int b, const int (&m)[NV], const int t, float (&v)[NV]) {
+    bool ok[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) ok[i] = m[i] < g.M && t < g.T;
+    if (g.mask) {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(g.mask + (size_t)b * g.k_sb);
+        float k[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) k[i] = bld1(r, ok[i] ? (unsigned)((m[i] * g.k_sm + t) * 4) : SWN_OOB);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) if (!(k[i] > 0.f)) v[i] = 0.f;
+    }
+    if (g.ymul) {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(g.ymul + (size_t)b * g.ym_sb);
+        float k[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) k[i] = bld1(r, ok[i] ? (unsigned)((m[i] * g.ym_sm + t) * 4) : SWN_OOB);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] *= k[i];
+    }
+    if (g.accumulate) {
+        const __amdgpu_buffer_rsrc_t r = rsrc_of(g.Y + (size_t)b * g.y_sb);
+        float k[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) k[i] = bld1(r, ok[i] ? (unsigned)((m[i] * g.y_sm + t) * 4) : SWN_OOB);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] += k[i];
+    }
+    float* Y = g.Y + (size_t)b * g.y_sb + t;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) if (ok[i]) Y[(size_t)m[i] * g.y_sm] = v[i];
+}
+
 // 64(m) x 64(t) tile, BK = 16 over k = (tap, c); product on the matrix cores (swn_mma.hpp); NST k-tiles of operand
 // loads in flight per thread.
 template <bool XMUL>
@@ -106,19 +144,12 @@ __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
         }
     }
     const int t = t0 + swn_mma_col(lane, w);
-    if (t >= g.T) return;
+    int mrow[16]; float v[16];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + swn_mma_row(lane, mt, i);
-            if (m >= g.M) continue;
-            float v = acc[mt][i];
-            if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
-            if (g.ymul) v *= g.ymul[(size_t)b * g.ym_sb + (size_t)m * g.ym_sm + t];
-            float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
-            *y = g.accumulate ? *y + v : v;
-        }
+        for (int i = 0; i < 4; ++i) { mrow[4 * mt + i] = m0 + swn_mma_row(lane, mt, i); v[4 * mt + i] = acc[mt][i]; }
+    tg_epilogue<16>(g, b, mrow, t, v);
 }
 
 // bf16-operand twin of time_gemm_kernel (swn_train_set_precision(1)): same operands in HBM (fp32), rounded to bf16 on
@@ -187,19 +218,12 @@ __global__ __launch_bounds__(256) void time_gemm_bf16_kernel(const TimeGemm g) {
         }
     }
     const int t = t0 + swn_mma_col(lane, w);
-    if (t >= g.T) return;
+    int mrow[16]; float v[16];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + swn_mma_row(lane, mt, i);
-            if (m >= g.M) continue;
-            float v = acc[mt][i];
-            if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
-            if (g.ymul) v *= g.ymul[(size_t)b * g.ym_sb + (size_t)m * g.ym_sm + t];
-            float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
-            *y = g.accumulate ? *y + v : v;
-        }
+        for (int i = 0; i < 4; ++i) { mrow[4 * mt + i] = m0 + swn_mma_row(lane, mt, i); v[4 * mt + i] = acc[mt][i]; }
+    tg_epilogue<16>(g, b, mrow, t, v);
 }
 
 // Third form of the time contraction (bf16 mode, KC % 32 == 0, time-contiguous X, no mask on X): workgroup tile
@@ -298,22 +322,19 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
         __syncthreads();
     }
     const int kq = lane >> 4, rc = lane & 15;
+    int mrow[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mrow[4 * i + e] = m0 + 64 * wm + 16 * i + 4 * kq + e;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int t = t0 + 64 * wn + 16 * j + rc;
-        if (t >= g.T) continue;
+        float v[16];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + 64 * wm + 16 * i + 4 * kq + e;
-                if (m >= g.M) continue;
-                float v = acc[i][j][e];
-                if (g.mask && !(g.mask[(size_t)b * g.k_sb + (size_t)m * g.k_sm + t] > 0.f)) v = 0.f;
-                if (g.ymul) v *= g.ymul[(size_t)b * g.ym_sb + (size_t)m * g.ym_sm + t];
-                float* y = g.Y + (size_t)b * g.y_sb + (size_t)m * g.y_sm + t;
-                *y = g.accumulate ? *y + v : v;
-            }
+            for (int e = 0; e < 4; ++e) v[4 * i + e] = acc[i][j][e];
+        tg_epilogue<16>(g, b, mrow, t0 + 64 * wn + 16 * j + rc, v);
     }
 }
 
