@@ -13,6 +13,7 @@
 // are recomputed (one extra conv GEMM per layer) instead of being stored.
 #include <hip/hip_runtime.h>
 #include <atomic>
+#include <stdlib.h>
 #include "swn_geom.hpp"
 #include "swn_mma.hpp"
 
@@ -346,6 +347,7 @@ struct ReduceGemm {
     int M, taps, KC, T, sgn, center, dil, TS;       // TS: time positions per block
     const float* qmul; long qm_sb, qm_sc;           // optional: Q[b][c][t] is read as Q * qmul[b][c][t]
     int QT;                                         // Q is valid on [0, QT) (0: same as T)
+    int nsegtot;                                    // batch * time segments (set by the launcher)
 };
 
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
@@ -619,6 +621,142 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16d_kernel(const ReduceGemm
     }
 }
 
+// The same contraction with the workgroup's 128 x 128 tile shared through LDS: every operand byte is fetched once per
+// workgroup instead of once per wave (the direct form is bound by the L1 path: 64 KB per step against 256 MFMA
+// cycles).  A thread fetches 16-byte time-quads (8 lanes = one 128-byte row segment), rounds them to bf16 and stores
+// 8 bytes into LDS; double-buffered, one barrier per step of 32 positions.
+__global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm g) {
+    __shared__ __attribute__((aligned(16))) unsigned Ps[2][128][SWN_MMB_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned Qs[2][128][SWN_MMB_PITCH];
+    // XCD-aware order (1-D grid; workgroup id i runs on XCD i % 8): the mt*nt tiles that read the same time segment are
+    // dispatched back to back on ONE XCD and walk the segment together, so its rows come out of HBM once per segment
+    // and are shared in that XCD's L2 instead of being fetched by up to eight L2s.
+    const int nseg = (g.T + g.TS - 1) / g.TS;
+    const int Nc = g.taps * g.KC;
+    const int mtl = (g.M + 127) / 128, ntl = (Nc + 127) / 128, per_seg = mtl * ntl;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int sg = (idx / per_seg) * 8 + xcd, tile = idx - (idx / per_seg) * per_seg;
+    if (sg >= g.nsegtot) return;
+    const int b = sg / nseg, ts0 = (sg - b * nseg) * g.TS;
+    const int by = tile / mtl, bx = tile - by * mtl;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const int m0 = bx * 128, n0 = by * 128;
+    const __amdgpu_buffer_rsrc_t rP = rsrc_of(g.P + (size_t)b * g.p_sb), rQ = rsrc_of(g.Q + (size_t)b * g.q_sb);
+    const int tend = ts0 + g.TS < g.T ? ts0 + g.TS : g.T;
+    const int QT = g.QT ? g.QT : g.T;
+    const int smax = (g.taps - 1) * g.dil;
+    const int q4 = tid & 7, r0 = tid >> 3;                  // staging: time-quad q4 of rows / columns r0 + 32 i
+    unsigned prow[4], qrow[4]; int qsh[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        prow[i] = m < g.M ? (unsigned)(m * g.p_sm * 4) : SWN_OOB;
+        const int n = n0 + r0 + 32 * i;
+        const int tap = n / g.KC, c = n - tap * g.KC;
+        qsh[i] = g.sgn * (tap - g.center) * g.dil;
+        qrow[i] = n < Nc ? (unsigned)((c * g.q_sc + qsh[i]) * 4) : SWN_OOB;     // modular: may be "negative"
+    }
+    swn_f32x4 acc[4][4] = {};
+    float rs[4] = {0.f, 0.f, 0.f, 0.f};
+    swn_fl4 ra[2][4], rb[2][4];              // two steps of operands in flight (HBM latency is ~10 steps of MFMA work)
+    auto load_fast = [&](int t, swn_fl4 (&ra)[4], swn_fl4 (&rb)[4]) {
+        const unsigned to = (unsigned)((t + 4 * q4) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ra[i] = bld4(rP, prow[i] + to);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) rb[i] = bld4(rQ, qrow[i] + to);
+    };
+    auto load_edge = [&](int t, swn_fl4 (&ra)[4], swn_fl4 (&rb)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int te = t + 4 * q4 + e;
+                const bool okp = te < tend;
+                const int tsrc = te + qsh[i];
+                const bool okq = okp && tsrc >= 0 && tsrc < QT && qrow[i] != SWN_OOB;
+                ra[i][e] = bld1(rP, okp ? prow[i] + (unsigned)(te * 4) : SWN_OOB);
+                rb[i][e] = bld1(rQ, okq ? qrow[i] + (unsigned)(te * 4) : SWN_OOB);
+            }
+    };
+    auto stage = [&](int buf, const swn_fl4 (&ra)[4], const swn_fl4 (&rb)[4]) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            rs[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+            const u2 vp = {swn_pack_bf16(ra[i].x, ra[i].y), swn_pack_bf16(ra[i].z, ra[i].w)};
+            const u2 vq = {swn_pack_bf16(rb[i].x, rb[i].y), swn_pack_bf16(rb[i].z, rb[i].w)};
+            *reinterpret_cast<u2*>(&Ps[buf][r0 + 32 * i][2 * q4]) = vp;
+            *reinterpret_cast<u2*>(&Qs[buf][r0 + 32 * i][2 * q4]) = vq;
+        }
+    };
+    auto mma = [&](int buf) {
+        const int kq = lane >> 4, rc = lane & 15;
+        swn_bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = *reinterpret_cast<const swn_bf16x8*>(&Ps[buf][64 * wm + 16 * i + rc][4 * kq]);
+            fb[i] = *reinterpret_cast<const swn_bf16x8*>(&Qs[buf][64 * wn + 16 * i + rc][4 * kq]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    // steps [sa, sb) are interior: every shifted 32-window inside [0, QT) and inside the segment
+    const int nsteps = (tend - ts0 + 31) / 32;
+    int sa = ts0 >= smax ? 0 : (smax - ts0 + 31) / 32;
+    const int lim = QT - smax < tend ? QT - smax : tend;          // t + 32 <= lim
+    int sb = lim - ts0 >= 32 ? (lim - ts0) / 32 : 0;
+    if (sa > nsteps) sa = nsteps;
+    if (sb > nsteps) sb = nsteps;
+    if (sb < sa) sb = sa;
+    for (int sidx = 0; sidx < sa; ++sidx) { load_edge(ts0 + 32 * sidx, ra[0], rb[0]); stage(0, ra[0], rb[0]); __syncthreads(); mma(0); __syncthreads(); }
+    if ((sb - sa) & 1) { load_fast(ts0 + 32 * sa, ra[0], rb[0]); stage(0, ra[0], rb[0]); __syncthreads(); mma(0); __syncthreads(); ++sa; }
+    if (sb > sa) {
+        const int last = sb - 1;                            // an even number of interior steps from here on
+        load_fast(ts0 + 32 * sa, ra[0], rb[0]);
+        load_fast(ts0 + 32 * (sa + 1), ra[1], rb[1]);
+        for (int sidx = sa; sidx < sb; sidx += 2) {         // loads past the end re-read the last step: harmless, branch-free
+            stage(0, ra[0], rb[0]);
+            __syncthreads();
+            load_fast(ts0 + 32 * (sidx + 2 < sb ? sidx + 2 : last), ra[0], rb[0]);
+            mma(0);
+            stage(1, ra[1], rb[1]);
+            __syncthreads();
+            load_fast(ts0 + 32 * (sidx + 3 < sb ? sidx + 3 : last), ra[1], rb[1]);
+            mma(1);
+        }
+        __syncthreads();
+    }
+    for (int sidx = sb; sidx < nsteps; ++sidx) { load_edge(ts0 + 32 * sidx, ra[0], rb[0]); stage(0, ra[0], rb[0]); __syncthreads(); mma(0); __syncthreads(); }
+
+    if (g.gb && by == 0) {          // bias gradient: a row's eight time-quads sit in eight neighbouring lanes
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4);
+            const int m = m0 + r0 + 32 * i;
+            if (q4 == 0 && m < g.M) atomicAdd(g.gb + m, v);
+        }
+    }
+    const int kq = lane >> 4, rc = lane & 15;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + 64 * wn + 16 * j + rc;
+        if (n >= Nc) continue;
+        const int tap = n / g.KC, c = n - tap * g.KC;
+        float* Gn = g.G + tap * g.g_stap + c * g.g_sc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int m = m0 + 64 * wm + 16 * i + 4 * kq + e;
+                if (m < g.M) atomicAdd(Gn + m * g.g_sm, acc[i][j][e]);
+            }
+    }
+}
+
 // ---- gate backward: recomputed pre-activations a (B,2H,T) -> da, dgx (in place over a / second buffer),
 //      and the highway carry  dh_prev += dh * z.      (cswnv_shift1.py:276-278)
 struct GateBwd {
@@ -832,7 +970,11 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
             if (want < 1) want = 1;
             g.TS = (((g.T + want - 1) / want) + 31) & ~31;
             const int ns = (g.T + g.TS - 1) / g.TS;
-            hipLaunchKernelGGL(reduce_gemm_bf16d_kernel, dim3(mt, nt, B * ns), dim3(256), 0, st, g);
+            if (getenv("SWN_REDUCE_DIRECT")) hipLaunchKernelGGL(reduce_gemm_bf16d_kernel, dim3(mt, nt, B * ns), dim3(256), 0, st, g);
+            else {
+                g.nsegtot = B * ns;
+                hipLaunchKernelGGL(reduce_gemm_bf16s_kernel, dim3((unsigned)(mt * nt * ((g.nsegtot + 7) / 8) * 8)), dim3(256), 0, st, g);
+            }
             return;
         }
         if (g.qmul) hipLaunchKernelGGL(reduce_gemm_bf16_kernel<true>, grid, dim3(256), 0, st, g);
