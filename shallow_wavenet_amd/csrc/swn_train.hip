@@ -31,6 +31,7 @@ struct TimeGemm {
     const float* xmul; long xm_sb, xm_sc;           // X[b][c][t] is read as X * xmul[b][c][t]
     const float* ymul; long ym_sb, ym_sm;           // the result is scaled by ymul[b][m][t] before it is stored / added
     int XT;                                         // X is valid on [0, XT) (0: same as T)
+    int nb;                                         // batch size (set by the launcher of the XCD-ordered kernel)
 };
 
 // Operand loads of the tiled kernels: through buffer resources with 32-bit byte offsets.  Whatever must read as
@@ -239,7 +240,16 @@ template <bool AKC>
 __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) {
     __shared__ __attribute__((aligned(16))) unsigned As[128][SWN_MMB_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned Bs[128][SWN_MMB_PITCH];
-    const int b = blockIdx.z, t0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    // XCD-aware order (1-D grid; workgroup id i runs on XCD i % 8): each XCD walks a contiguous range of time tiles,
+    // the row tiles of one time tile back to back - they read the same X window, and neighbouring time tiles share
+    // their tap halos (up to (K-1)*dil positions, more than the tile itself at dil 49) in that XCD's L2.
+    const int ntt = (g.T + 127) / 128, mtl = (g.M + 127) / 128;
+    const int chunk = (ntt * g.nb + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ttl = idx / mtl, mtile = idx - ttl * mtl;
+    const int gt = xcd * chunk + ttl;
+    if (ttl >= chunk || gt >= ntt * g.nb) return;
+    const int b = gt / ntt, t0 = (gt - b * ntt) * 128, m0 = mtile * 128;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(g.A), 0, 0x40000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = rsrc_of(g.X + (size_t)b * g.x_sb);
@@ -944,9 +954,12 @@ void launch_time(const TimeGemm& g, int B, hipStream_t st) {
     const dim3 grid((g.T + 63) / 64, (g.M + 63) / 64, B);
     if (g_train_bf16.load(std::memory_order_relaxed)) {
         if (!g.xmul && g.x_st == 1 && g.KC % 32 == 0) {
-            const dim3 big((g.T + 127) / 128, (g.M + 127) / 128, B);
-            if (g.a_sc == 1) hipLaunchKernelGGL(time_gemm_bf16t_kernel<true>, big, dim3(256), 0, st, g);
-            else hipLaunchKernelGGL(time_gemm_bf16t_kernel<false>, big, dim3(256), 0, st, g);
+            TimeGemm h = g;
+            h.nb = B;
+            const int chunk = (((g.T + 127) / 128) * B + 7) / 8;
+            const dim3 big((unsigned)(8 * chunk * ((g.M + 127) / 128)));
+            if (g.a_sc == 1) hipLaunchKernelGGL(time_gemm_bf16t_kernel<true>, big, dim3(256), 0, st, h);
+            else hipLaunchKernelGGL(time_gemm_bf16t_kernel<false>, big, dim3(256), 0, st, h);
             return;
         }
         if (g.xmul) hipLaunchKernelGGL(time_gemm_bf16_kernel<true>, grid, dim3(256), 0, st, g);
