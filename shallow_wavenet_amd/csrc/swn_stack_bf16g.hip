@@ -45,6 +45,7 @@ struct GemmArgs {
     size_t o_bd, o_bx, o_wup, o_wxa;
     int H, l, seg, U, Tf, N, coff;
     const int* aidx; int Q;                        // softmax audio_in: class index of position t, or null
+    int ntt, nmt;                                  // time tiles per utterance, row tiles (set by launch_gemm)
 };
 
 template <int EPI, int WNT>      // WNT: 16-column accumulator tiles per wave; the workgroup tile is 128 rows x 32*WNT positions
@@ -53,11 +54,20 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned short As[TM * PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[TNW * PITCH];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int t0 = blockIdx.x * TNW, m0 = blockIdx.y * TM, b = blockIdx.z;
+    // XCD-aware order (1-D grid; workgroup id i runs on XCD i % 8): each XCD walks a contiguous range of time tiles, the
+    // row tiles of one time tile back to back: they read the same activations, and neighbouring time tiles share their
+    // tap halos ((K-1)*dil positions) in that XCD's L2 instead of fetching them into eight L2s.
+    const int chunk = (a.ntt * a.B + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ttl = idx / a.nmt, by = idx - ttl * a.nmt;
+    const int gt = xcd * chunk + ttl;
+    if (ttl >= chunk || gt >= a.ntt * a.B) return;
+    const int b = gt / a.ntt;
+    const int t0 = (gt - b * a.ntt) * TNW, m0 = by * TM;
     // tile row -> matrix row
     auto rowmap = [&](int tr) -> int {
         if (EPI != EPI_GATE) return m0 + tr;
-        const int c0 = blockIdx.y * 64, wmr = tr >> 6, mt = (tr & 63) >> 4, r = tr & 15;
+        const int c0 = by * 64, wmr = tr >> 6, mt = (tr & 63) >> 4, r = tr & 15;
         const int ch = c0 + 32 * wmr + 16 * (mt >> 1) + r;
         return ch < a.H ? (mt & 1) * a.H + ch : -1;
     };
@@ -137,7 +147,7 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
             if (t >= a.Tp) continue;
 #pragma unroll
             for (int p = 0; p < 2; ++p) {
-                const int ch = blockIdx.y * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
+                const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
                 if (ch >= H) continue;
                 float gz[4], gc[4];
 #pragma unroll
@@ -254,6 +264,14 @@ GOff g_offsets(const SwnGeom& g) {
     return o;
 }
 
+template <int EPI>
+void launch_gemm(GemmArgs a, int ntt, int nmt, int batch, hipStream_t st) {
+    constexpr int WNT = 4;
+    a.ntt = ntt; a.nmt = nmt;
+    const int chunk = (ntt * batch + 7) / 8;
+    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI, WNT>), dim3((unsigned)(8 * chunk * nmt)), dim3(256), 0, st, a);
+}
+
 }  // namespace
 
 // geometry class of this file: Laplace or softmax, H a multiple of 64 (row tiles of 64 channels, k-tiles of 32), S and O1
@@ -367,18 +385,18 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
         a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K; a.src_bytes = lstride * 2;
         a.shift0 = (g.K - 1) * g.dil[l]; a.shift_step = g.dil[l];
         a.hprev = hs + (size_t)l * lstride; a.hnext = hs + (size_t)(l + 1) * lstride; a.l = l;
-        hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_GATE, WNT>), dim3(tx, g.H / 64, batch), dim3(256), 0, st, a);
+        launch_gemm<EPI_GATE>(a, (int)tx, g.H / 64, batch, st);
     }
     // skip = relu(Wsk . [h_1 .. h_L] + b)
     a.A = wbf + o.wsk; a.M = g.S; a.Kd = g.L * g.H; a.src = hs + lstride; a.blk_stride = lstride; a.KB = g.H; a.nblk = g.L;
     a.src_bytes = (size_t)g.L * lstride * 2;
     a.shift0 = 0; a.shift_step = 0; a.bias = packed + y.bsk; a.out_bf = skipb; a.out_ld = g.S;
-    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_RELU_BF16, WNT>), dim3(tx, (g.S + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    launch_gemm<EPI_RELU_BF16>(a, (int)tx, (g.S + TM - 1) / TM, batch, st);
     a.A = wbf + o.w1; a.M = g.O1; a.Kd = g.S; a.src = skipb; a.blk_stride = 0; a.KB = g.S; a.nblk = 1; a.src_bytes = (size_t)batch * Tp * g.S * 2;
     a.bias = packed + y.b1; a.out_bf = o1b; a.out_ld = g.O1;
-    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_RELU_BF16, WNT>), dim3(tx, (g.O1 + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    launch_gemm<EPI_RELU_BF16>(a, (int)tx, (g.O1 + TM - 1) / TM, batch, st);
     a.A = wbf + o.w2; a.M = g.NO; a.Kd = g.O1; a.src = o1b; a.KB = g.O1; a.nblk = 1; a.src_bytes = (size_t)batch * Tp * g.O1 * 2;
     a.bias = packed + y.b2; a.out_f = out; a.NO = g.NO;
-    hipLaunchKernelGGL((bf16g_gemm_kernel<EPI_F32, WNT>), dim3(tx, (g.NO + TM - 1) / TM, batch), dim3(256), 0, st, a);
+    launch_gemm<EPI_F32>(a, (int)tx, (g.NO + TM - 1) / TM, batch, st);
     return swn_launch_status("swn_forward_bf16");
 }
