@@ -831,20 +831,26 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
 }
 
 // ---- hoisted conditioning backward, two orientations of the same (frame x tap) product:
-//      cond_bwd_kernel  thread = in_x row o2:  dcond[b][f][(l*seg+s)*2H+o2] = sum_jj w_up[jj] * dgx[o2][t] ; gbx
-//      wup_bwd_kernel   thread = upsampler tap jj:  gwup[jj] += sum_{s,o2} dgx[o2][t] * cond[b][f][(l*seg+s)*2H+o2]
+//      threads 0..63    thread = in_x row o2:  dcond[b][f][(l*seg+s)*2H+o2] = sum_jj w_up[jj] * dgx[o2][t] ; gbx
+//      threads 64..255  thread = upsampler tap jj:  gwup[jj] += sum_{s,o2} dgx[o2][t] * cond[b][f][(l*seg+s)*2H+o2]
 //      with t = f*U + jj - s - coff  (the positions whose conditioning comes from frame f, tap jj)
-__global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* __restrict__ dcond, float* __restrict__ gbx) {
+__global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* __restrict__ dcond, float* __restrict__ gbx,
+                                                       float* __restrict__ gwup) {
     // workgroup = (64 in_x rows, frame f, utterance b).  The U + seg - 1 positions the frame touches are staged
     // through LDS with coalesced loads (lanes along t; it used to be one strided stream per thread, thrashing L1),
     // then one thread per row does its U x seg multiply-adds out of LDS (row pitch odd: conflict-free).
     __shared__ float tile[64][256 + 16 + 1];
     __shared__ float wus[256];
+    __shared__ float cs[10][64];                 // seg <= 10 (swn_make_geom)
     const SwnGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, f = blockIdx.y, b = blockIdx.z;
     const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
     const int tbeg = f * U - (seg - 1) - a.coff, ncol = U + seg - 1;           // tile column c <-> position tbeg + c
     wus[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
+    for (int e = tid; e < seg * 64; e += 256) {                                 // this frame's in_x products for the 64 rows
+        const int sx = e >> 6, o2 = blockIdx.x * 64 + (e & 63);
+        cs[sx][e & 63] = o2 < H2 ? a.cond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + sx) * H2 + o2] : 0.f;
+    }
     for (int r = w; r < 64; r += 4) {
         const int o2 = blockIdx.x * 64 + r;
         const float* dg = a.dgx + ((size_t)b * H2 + (o2 < H2 ? o2 : 0)) * a.Tp;
@@ -854,8 +860,22 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
         }
     }
     __syncthreads();
+    if (tid >= 64) {
+        // the other orientation of the same tile (was a second pass over dgx, wup_bwd_kernel): thread = upsampler tap jj,
+        // gwup[jj] += sum_{s, rows} dgx[row][t(jj, s)] * cond[f][(l*seg+s)*2H + row]   (columns: conflict-free, pitch odd)
+        for (int jj = tid - 64; jj < U; jj += 192) {
+            float acc = 0.f;
+            for (int sx = 0; sx < seg; ++sx) {
+                const int c = jj + (seg - 1) - sx;
+#pragma unroll 8
+                for (int r = 0; r < 64; ++r) acc = fmaf(tile[r][c], cs[sx][r], acc);
+            }
+            atomicAdd(gwup + jj, acc);
+        }
+        return;
+    }
     const int o2 = blockIdx.x * 64 + tid;
-    if (tid >= 64 || o2 >= H2) return;
+    if (o2 >= H2) return;
     float bsum = 0.f;
     for (int s = 0; s < seg; ++s) {
         float dsum = 0.f;
@@ -869,22 +889,6 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     atomicAdd(gbx + (size_t)l * H2 + o2, bsum);
 }
 
-__global__ __launch_bounds__(256) void wup_bwd_kernel(const GateBwd a, float* __restrict__ gwup) {
-    const SwnGeom& g = a.g;
-    const int jj = threadIdx.x, f = blockIdx.x, b = blockIdx.y;
-    const int H2 = 2 * g.H, l = a.l, seg = g.seg;
-    if (jj >= g.U) return;
-    const float* condb = a.cond + ((size_t)b * a.Tf + f) * g.N;
-    float acc = 0.f;
-    for (int s = 0; s < seg; ++s) {
-        const int t = f * g.U + jj - s - a.coff;
-        if (t < 0 || t >= a.Tp) continue;
-        const float* dg = a.dgx + (size_t)b * H2 * a.Tp + t;
-        const float* cr = condb + (size_t)(l * seg + s) * H2;
-        for (int o2 = 0; o2 < H2; ++o2) acc = fmaf(dg[(size_t)o2 * a.Tp], cr[o2], acc);
-    }
-    atomicAdd(gwup + jj, acc);
-}
 
 // ---- input layer backward: dh0 -> gcb, gcv, gcc (laplace) | gct (softmax)
 template <int KIND>
@@ -1165,8 +1169,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             launch_time(t, B, st);
         }
         if (!drop) {
-            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 63) / 64, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx);
-            hipLaunchKernelGGL(wup_bwd_kernel, dim3(n_frames, B), dim3(256), 0, st, ga, gpacked + y.wup);
+            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 63) / 64, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx,
+                               gpacked + y.wup);
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
             {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
