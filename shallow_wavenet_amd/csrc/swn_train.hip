@@ -851,12 +851,19 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
         const int sx = e >> 6, o2 = blockIdx.x * 64 + (e & 63);
         cs[sx][e & 63] = o2 < H2 ? a.cond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + sx) * H2 + o2] : 0.f;
     }
-    for (int r = w; r < 64; r += 4) {
-        const int o2 = blockIdx.x * 64 + r;
-        const float* dg = a.dgx + ((size_t)b * H2 + (o2 < H2 ? o2 : 0)) * a.Tp;
+    {   // 16 rows per wave, all 16 loads of a 64-column chunk in flight (branch-free: out-of-range offset = zero)
+        const __amdgpu_buffer_rsrc_t rD = rsrc_of(a.dgx + (size_t)b * H2 * a.Tp);
         for (int c = lane; c < ncol; c += 64) {
             const int t = tbeg + c;
-            tile[r][c] = (o2 < H2 && t >= 0 && t < a.Tp) ? dg[t] : 0.f;
+            const bool tok = t >= 0 && t < a.Tp;
+            float v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int o2 = blockIdx.x * 64 + w + 4 * i;
+                v[i] = bld1(rD, (tok && o2 < H2) ? (unsigned)(((size_t)o2 * a.Tp + t) * 4) : SWN_OOB);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) tile[w + 4 * i][c] = v[i];
         }
     }
     __syncthreads();
