@@ -50,3 +50,20 @@ __device__ __forceinline__ void swn_mmb_64x64x32(const unsigned (*As)[SWN_MMB_PI
         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[mt], 0, 0, 0);
     }
 }
+
+// Operand loads of the tiled kernels: through buffer resources with 32-bit byte offsets.  Whatever must read as
+// zero (k past the end, a row past M, a position outside [0, T)) is the out-of-range offset, so the loads need
+// neither branches nor selects - either would make the compiler drain the prefetch queue (s_waitcnt vmcnt(0)) at
+// every k-tile, which is what these kernels were bound by.  Every operand (per batch item) must be < 2 GiB.
+constexpr unsigned SWN_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_of(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+typedef float swn_fl4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ swn_fl4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(swn_fl4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+

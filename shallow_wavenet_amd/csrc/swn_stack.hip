@@ -95,33 +95,37 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
     int tapB[4], iB[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) { const int kd = (tid >> 6) + 4 * q; tapB[q] = kd / Hp; iB[q] = kd - tapB[q] * Hp; }
-    float4 ra; float rb[4];
-    auto fetch = [&](int k0) {
-        ra = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (oa < H && k0 + kq < Kd) ra = *reinterpret_cast<const float4*>(wrow + k0 + kq);
+    // operand loads through buffer resources, out-of-range offset = zero: no branch and no select touches a load, so
+    // two k-tiles stay in flight under the MFMAs (a conditional load is an exec-masked branch + s_waitcnt vmcnt(0))
+    const __amdgpu_buffer_rsrc_t rW = rsrc_of(W), rH = rsrc_of(hprev);
+    const __amdgpu_buffer_rsrc_t rM = rsrc_of(in_mul ? in_mul + (size_t)b * H * a.Tp : hprev);
+    const unsigned wbase = oa < H ? (unsigned)((size_t)((rr < 32) ? oa : H + oa) * Kd * 4) + (unsigned)(kq * 4) : SWN_OOB;
+    swn_fl4 ra[2]; float rb[2][4], rm[2][4];
+    auto fetch = [&](int k0, swn_fl4& qa, float (&qb)[4], float (&qm)[4]) {
+        qa = bld4(rW, k0 + kq < Kd ? wbase + (unsigned)(k0 * 4) : SWN_OOB);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            float v = 0.f;
-            if (k0 + (tid >> 6) + 4 * q < Kd && iB[q] < H && tok) {
-                const int ts = t0 + tt - (K - 1 - tapB[q]) * dil;
-                if (ts >= 0) {
-                    v = hprev[(size_t)iB[q] * a.Tp + ts];
-                    if (in_mul) v *= in_mul[((size_t)b * H + iB[q]) * a.Tp + ts];       // input = dropped output of layer l-1
-                }
-            }
-            rb[q] = v;
+            const int ts = t0 + tt - (K - 1 - tapB[q]) * dil;
+            const bool ok = k0 + (tid >> 6) + 4 * q < Kd && iB[q] < H && tok && ts >= 0;
+            const unsigned off = ok ? (unsigned)(((size_t)iB[q] * a.Tp + ts) * 4) : SWN_OOB;
+            qb[q] = bld1(rH, off);
+            qm[q] = in_mul ? bld1(rM, off) : 1.f;       // input = dropped output of layer l-1 (uniform branch)
             iB[q] += 16; while (iB[q] >= Hp) { iB[q] -= Hp; ++tapB[q]; }
         }
     };
-    fetch(0);
-    for (int k0 = 0; k0 < Kd; k0 += 16) {
-        As[kq + 0][rr] = ra.x; As[kq + 1][rr] = ra.y; As[kq + 2][rr] = ra.z; As[kq + 3][rr] = ra.w;
+    fetch(0, ra[0], rb[0], rm[0]);
+    fetch(16, ra[1], rb[1], rm[1]);
+    for (int k0 = 0; k0 < Kd; k0 += 32) {                 // a k-tile past Kd is all zeros
 #pragma unroll
-        for (int q = 0; q < 4; ++q) Bs[(tid >> 6) + 4 * q][tt] = rb[q];
-        __syncthreads();
-        if (k0 + 16 < Kd) fetch(k0 + 16);
-        swn_mma_64x64x16(As, Bs, acc, lane, w);
-        __syncthreads();
+        for (int u = 0; u < 2; ++u) {
+            As[kq + 0][rr] = ra[u].x; As[kq + 1][rr] = ra[u].y; As[kq + 2][rr] = ra[u].z; As[kq + 3][rr] = ra[u].w;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) Bs[(tid >> 6) + 4 * q][tt] = rb[u][q] * rm[u][q];
+            __syncthreads();
+            fetch(k0 + 16 * (u + 2), ra[u], rb[u], rm[u]);
+            swn_mma_64x64x16(As, Bs, acc, lane, w);
+            __syncthreads();
+        }
     }
     // ---- epilogue: conditioning (hoisted in_x + rank-1 upsampler), gate, highway.  A lane holds, for its position
     //      t, the gate rows (M-tiles 0,1) and the candidate rows (M-tiles 2,3) of the same 8 channels.
