@@ -182,25 +182,32 @@ __global__ __launch_bounds__(256) void gemm_wx_kernel(const float* __restrict__ 
     const float* Xb = X + (size_t)b * xstride_b;
     float* Yb = Y + (size_t)b * ystride_b;
     swn_f32x4 acc[4] = {};
-    for (int k0 = 0; k0 < Kd; k0 += 16) {
-        {
-            const int rr = tid >> 2, kq = (tid & 3) * 4;
-            const int m = m0 + rr;
-            float v[4] = {0.f, 0.f, 0.f, 0.f};
-            if (m < M) {
+    // operands through buffer resources (out-of-range offset = zero), two k-tiles of loads in flight under the MFMAs
+    const __amdgpu_buffer_rsrc_t rW = rsrc_of(W), rX = rsrc_of(Xb);
+    const int rr = tid >> 2, kq = (tid & 3) * 4, tt = tid & 63, kb = tid >> 6;
+    const unsigned wrow = m0 + rr < M ? (unsigned)((size_t)(m0 + rr) * ldw * 4) : SWN_OOB;
+    const bool tok = t0 + tt < T;
+    float ra[2][4], rb[2][4];
+    auto fetch = [&](int k0, float (&qa)[4], float (&qb)[4]) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    if (k0 + kq + e < Kd) v[e] = W[(size_t)m * ldw + k0 + kq + e];
-            }
-            As[kq + 0][rr] = v[0]; As[kq + 1][rr] = v[1]; As[kq + 2][rr] = v[2]; As[kq + 3][rr] = v[3];
+        for (int e = 0; e < 4; ++e) {
+            qa[e] = bld1(rW, (wrow != SWN_OOB && k0 + kq + e < Kd) ? wrow + (unsigned)((k0 + kq + e) * 4) : SWN_OOB);
+            const int kk = k0 + kb + 4 * e;
+            qb[e] = bld1(rX, (kk < Kd && tok) ? (unsigned)(((size_t)kk * T + t0 + tt) * 4) : SWN_OOB);
         }
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e >> 6, tt = e & 63;
-            Bs[kk][tt] = (k0 + kk < Kd && t0 + tt < T) ? Xb[(size_t)(k0 + kk) * T + t0 + tt] : 0.f;
+    };
+    fetch(0, ra[0], rb[0]);
+    fetch(16, ra[1], rb[1]);
+    for (int k0 = 0; k0 < Kd; k0 += 32) {                 // a k-tile past Kd is all zeros
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { As[kq + e][rr] = ra[u][e]; Bs[kb + 4 * e][tt] = rb[u][e]; }
+            __syncthreads();
+            fetch(k0 + 16 * (u + 2), ra[u], rb[u]);
+            swn_mma_64x64x16(As, Bs, acc, lane, w);
+            __syncthreads();
         }
-        __syncthreads();
-        swn_mma_64x64x16(As, Bs, acc, lane, w);
-        __syncthreads();
     }
     const int t = t0 + swn_mma_col(lane, w);
     if (t >= T) return;
@@ -295,6 +302,15 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
     const long T = (long)n_frames * g.U;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     if (Tp < 1) return SWN_E_BADARG;
+    {   // the tiled kernels address one utterance's operands with 32-bit byte offsets
+        size_t widest = (size_t)(g.L + 1) * g.H;
+        if ((size_t)g.S > widest) widest = g.S;
+        if ((size_t)g.O1 > widest) widest = g.O1;
+        if (widest * Tp * sizeof(float) >= (1ull << 31)) {
+            swn_set_error_detail(where, "one utterance's activations exceed 2 GiB: split the chunk");
+            return SWN_E_UNSUPPORTED;
+        }
+    }
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported
     const size_t hs_floats = r64((size_t)batch * (g.L + 1) * g.H * Tp);

@@ -1072,6 +1072,16 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const long T = (long)n_frames * g.U;
     const int Tp = (int)(g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1);
     if (Tp < 1) return SWN_E_BADARG;
+    {   // the contraction kernels address one utterance's operands with 32-bit byte offsets
+        size_t widest = (size_t)(g.L + 1) * g.H;
+        if ((size_t)g.S > widest) widest = g.S;
+        if ((size_t)g.O1 > widest) widest = g.O1;
+        if ((size_t)g.A0 > widest) widest = g.A0;
+        if (widest * (size_t)T * sizeof(float) >= (1ull << 31)) {
+            swn_set_error_detail(where, "one utterance's activations exceed 2 GiB: split the chunk");
+            return SWN_E_UNSUPPORTED;
+        }
+    }
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();
     const int B = batch, H = g.H, H2 = 2 * g.H, L = g.L, S = g.S, O1 = g.O1, NO = g.NO;
