@@ -13,7 +13,6 @@
 // are recomputed (one extra conv GEMM per layer) instead of being stored.
 #include <hip/hip_runtime.h>
 #include <atomic>
-#include <stdlib.h>
 #include "swn_geom.hpp"
 #include "swn_mma.hpp"
 
@@ -496,128 +495,10 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16_kernel(const ReduceGemm 
         }
 }
 
-// Second bf16 form of the weight-gradient contraction, for time-contiguous operands (p_st == q_st == 1, no mask):
-// the reduction index IS the contiguous axis of both operands, so an MFMA fragment (8 consecutive k of one row) is
-// 32 contiguous bytes of HBM - fragments go straight from two 16-byte loads to registers, no LDS and no barriers.
-// Workgroup = 2 x 2 waves, wave tile 64 x 64 (16 accumulators), one step = 32 time positions, the next step's 16
-// loads in flight under the 16 MFMAs of this one; rows shared by two waves meet in the CU's L1.  Steps whose shifted
-// window could leave [0, QT) or cross the segment end take the per-element loop (a handful per sequence).
-__device__ __forceinline__ swn_bf16x8 frag_bf16(const swn_fl4 lo, const swn_fl4 hi) {
-    typedef unsigned u4 __attribute__((ext_vector_type(4)));
-    const u4 v = {swn_pack_bf16(lo.x, lo.y), swn_pack_bf16(lo.z, lo.w), swn_pack_bf16(hi.x, hi.y), swn_pack_bf16(hi.z, hi.w)};
-    return __builtin_bit_cast(swn_bf16x8, v);
-}
-
-__global__ __launch_bounds__(256) void reduce_gemm_bf16d_kernel(const ReduceGemm g) {
-    const int nseg = (g.T + g.TS - 1) / g.TS;
-    const int b = blockIdx.z / nseg, ts0 = (blockIdx.z - b * nseg) * g.TS;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
-    const int m0 = blockIdx.x * 128 + 64 * wm, n0 = blockIdx.y * 128 + 64 * wn;
-    const int Nc = g.taps * g.KC;
-    const __amdgpu_buffer_rsrc_t rP = rsrc_of(g.P + (size_t)b * g.p_sb), rQ = rsrc_of(g.Q + (size_t)b * g.q_sb);
-    const int kq = lane >> 4, rc = lane & 15;
-    const int tend = ts0 + g.TS < g.T ? ts0 + g.TS : g.T;
-    const int QT = g.QT ? g.QT : g.T;
-    const int smax = (g.taps - 1) * g.dil;
-    // row bases as byte offsets; the out-of-range marker survives the additions below (every operand is < 2 GiB)
-    unsigned prow[4], qrow[4]; int qsh[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + 16 * i + rc;
-        prow[i] = m < g.M ? (unsigned)(m * g.p_sm * 4) : SWN_OOB;
-        const int n = n0 + 16 * i + rc;
-        const int tap = n / g.KC, c = n - tap * g.KC;
-        qsh[i] = g.sgn * (tap - g.center) * g.dil;
-        qrow[i] = n < Nc ? (unsigned)((c * g.q_sc + qsh[i]) * 4) : SWN_OOB;     // may be "negative": offsets are modular
-    }
-    swn_f32x4 acc[4][4] = {};
-    float rs[4] = {0.f, 0.f, 0.f, 0.f};
-    auto load_fast = [&](int t, swn_fl4 (&ra)[4][2], swn_fl4 (&rb)[4][2]) {
-        const unsigned to = (unsigned)((t + 8 * kq) * 4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { ra[i][0] = bld4(rP, prow[i] + to); ra[i][1] = bld4(rP, prow[i] + to + 16); }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { rb[i][0] = bld4(rQ, qrow[i] + to); rb[i][1] = bld4(rQ, qrow[i] + to + 16); }
-    };
-    auto load_edge = [&](int t, swn_fl4 (&ra)[4][2], swn_fl4 (&rb)[4][2]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int te = t + 8 * kq + e;
-                const bool okp = te < tend;
-                const int tsrc = te + qsh[i];
-                const bool okq = okp && tsrc >= 0 && tsrc < QT && qrow[i] != SWN_OOB;
-                ra[i][e >> 2][e & 3] = bld1(rP, okp ? prow[i] + (unsigned)(te * 4) : SWN_OOB);
-                rb[i][e >> 2][e & 3] = bld1(rQ, okq ? qrow[i] + (unsigned)(te * 4) : SWN_OOB);
-            }
-    };
-    auto step = [&](const swn_fl4 (&ra)[4][2], const swn_fl4 (&rb)[4][2]) {
-        swn_bf16x8 fa[4], fb[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const swn_fl4 s4 = ra[i][0] + ra[i][1];
-            rs[i] += (s4.x + s4.y) + (s4.z + s4.w);
-            fa[i] = frag_bf16(ra[i][0], ra[i][1]);
-            fb[i] = frag_bf16(rb[i][0], rb[i][1]);
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
-    // steps [sa, sb) are interior: every shifted 32-window inside [0, QT) and inside the segment
-    const int nsteps = (tend - ts0 + 31) / 32;
-    int sa = ts0 >= smax ? 0 : (smax - ts0 + 31) / 32;
-    int lim = QT - smax < tend ? QT - smax : tend;          // t + 32 <= lim
-    int sb = lim - ts0 >= 32 ? (lim - ts0) / 32 : 0;
-    if (sa > nsteps) sa = nsteps;
-    if (sb > nsteps) sb = nsteps;
-    if (sb < sa) sb = sa;
-    swn_fl4 ra[2][4][2], rb[2][4][2];
-    for (int sidx = 0; sidx < sa; ++sidx) { load_edge(ts0 + 32 * sidx, ra[0], rb[0]); step(ra[0], rb[0]); }
-    if (sb > sa) {
-        load_fast(ts0 + 32 * sa, ra[0], rb[0]);
-        int sidx = sa;
-        for (; sidx + 2 < sb; sidx += 2) {
-            load_fast(ts0 + 32 * (sidx + 1), ra[1], rb[1]);
-            step(ra[0], rb[0]);
-            load_fast(ts0 + 32 * (sidx + 2), ra[0], rb[0]);
-            step(ra[1], rb[1]);
-        }
-        if (sidx + 1 < sb) { load_fast(ts0 + 32 * (sidx + 1), ra[1], rb[1]); step(ra[0], rb[0]); step(ra[1], rb[1]); }
-        else step(ra[0], rb[0]);
-    }
-    for (int sidx = sb; sidx < nsteps; ++sidx) { load_edge(ts0 + 32 * sidx, ra[0], rb[0]); step(ra[0], rb[0]); }
-
-    if (g.gb && blockIdx.y == 0 && wn == 0) {       // bias gradient: a row's four k-quarters sit in lanes rc, rc+16, rc+32, rc+48
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            float v = rs[i];
-            v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
-            const int m = m0 + 16 * i + rc;
-            if (kq == 0 && m < g.M) atomicAdd(g.gb + m, v);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int n = n0 + 16 * j + rc;
-        if (n >= Nc) continue;
-        const int tap = n / g.KC, c = n - tap * g.KC;
-        float* Gn = g.G + tap * g.g_stap + c * g.g_sc;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int m = m0 + 16 * i + 4 * kq + e;
-                if (m < g.M) atomicAdd(Gn + m * g.g_sm, acc[i][j][e]);
-            }
-    }
-}
-
-// The same contraction with the workgroup's 128 x 128 tile shared through LDS: every operand byte is fetched once per
-// workgroup instead of once per wave (the direct form is bound by the L1 path: 64 KB per step against 256 MFMA
-// cycles).  A thread fetches 16-byte time-quads (8 lanes = one 128-byte row segment), rounds them to bf16 and stores
+// bf16 form of the weight-gradient contraction for time-contiguous operands (p_st == q_st == 1, no mask): the
+// reduction index IS the contiguous axis of both operands.  Workgroup tile 128 x 128 shared through LDS (a first cut
+// loaded MFMA fragments straight from HBM into registers, no LDS at all - bound by the L1 path, every wave fetching its
+// own copy: 64 KB per step against 256 MFMA cycles).  A thread fetches 16-byte time-quads (8 lanes = one 128-byte row segment), rounds them to bf16 and stores
 // 8 bytes into LDS; double-buffered, one barrier per step of 32 positions.
 __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm g) {
     __shared__ __attribute__((aligned(16))) unsigned Ps[2][128][SWN_MMB_PITCH];
@@ -970,7 +851,7 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
     const dim3 grid((g.M + 63) / 64, (g.taps * g.KC + 63) / 64, B * nseg);
     if (g_train_bf16.load(std::memory_order_relaxed)) {
         if (!g.qmul && g.p_st == 1 && g.q_st == 1 && g.T >= 256) {
-            // direct-fragment kernel: 128 x 128 tiles; time segments sized so that about a thousand workgroups exist
+            // 128 x 128 tiles; time segments sized so that about a thousand workgroups exist
             const int mt = (g.M + 127) / 128, nt = (g.taps * g.KC + 127) / 128;
             int want = (1024 + mt * nt * B - 1) / (mt * nt * B);
             const int most = (g.T + 255) / 256;
@@ -978,8 +859,7 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
             if (want < 1) want = 1;
             g.TS = (((g.T + want - 1) / want) + 31) & ~31;
             const int ns = (g.T + g.TS - 1) / g.TS;
-            if (getenv("SWN_REDUCE_DIRECT")) hipLaunchKernelGGL(reduce_gemm_bf16d_kernel, dim3(mt, nt, B * ns), dim3(256), 0, st, g);
-            else {
+            {
                 g.nsegtot = B * ns;
                 hipLaunchKernelGGL(reduce_gemm_bf16s_kernel, dim3((unsigned)(mt * nt * ((g.nsegtot + 7) / 8) * 8)), dim3(256), 0, st, g);
             }
