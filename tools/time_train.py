@@ -1,5 +1,5 @@
 """dev tool: one training step (forward + backward HIP kernels) at the BASELINE cfg4 shape.
-  python tools/time_train.py [B Tf [fp32|bf16]]   (third argument: arithmetic of the backward contractions)"""
+  python tools/time_train.py [B Tf [fp32|bf16 [bl6|ref6]]]   (third argument: arithmetic of the backward contractions)"""
 import sys, os
 _R = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, _R)
 import torch
@@ -11,7 +11,10 @@ B, Tf = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (8, 150)
 from shallow_wavenet_amd.runtime import train_precision
 MODE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 train_precision(MODE)
+ONLY = sys.argv[4].upper() if len(sys.argv) > 4 else None      # optional 4th argument: bl6 | ref6
 for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
+    if ONLY and nm != ONLY:
+        continue
     m = mc.CSWNV(**cfg.ctor_kwargs())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True).items()})
     m.cuda().train()
