@@ -7,6 +7,8 @@
 // All fp32 (decode parity needs fp32).  Frame-rate work is <1% of a decode.
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
+#include "swn_mma.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -21,22 +23,58 @@ __global__ __launch_bounds__(256) void conv1d_same_kernel(
     const int co0 = (blockIdx.y * 4 + cg) * CPT;
     const int b = blockIdx.z;
     if (co0 >= cout) return;
-    const float* inb = in + (size_t)b * cin * n_frames;
     float acc[CPT];
 #pragma unroll
     for (int r = 0; r < CPT; ++r) acc[r] = (co0 + r < cout) ? bias[co0 + r] : 0.f;
     const int half = (ks - 1) / 2;
-    for (int ci = 0; ci < cin; ++ci) {
-        for (int k = 0; k < ks; ++k) {
-            const int ff = f + (k - half) * dil;
-            const float x = (f < n_frames && ff >= 0 && ff < n_frames) ? inb[(size_t)ci * n_frames + ff] : 0.f;
+    // inputs through a buffer resource (out-of-range offset = zero padding), eight input channels x KS taps in flight;
+    // the multiply-adds keep the (ci ascending, k ascending) order of the plain loop
+    const __amdgpu_buffer_rsrc_t rI = rsrc_of(in + (size_t)b * cin * n_frames);
+    constexpr int CB = 8;
+    auto run = [&](auto ks_tag) {
+        constexpr int KS = decltype(ks_tag)::value;
+        unsigned toff[KS];
 #pragma unroll
-            for (int r = 0; r < CPT; ++r) {
-                const int co = co0 + r;                   // wave-uniform -> scalar weight load
-                const float wv = (co < cout) ? w[((size_t)co * cin + ci) * ks + k] : 0.f;
-                acc[r] = fmaf(wv, x, acc[r]);
+        for (int k = 0; k < KS; ++k) {
+            const int ff = f + (k - half) * dil;
+            toff[k] = (f < n_frames && ff >= 0 && ff < n_frames) ? (unsigned)(ff * 4) : SWN_OOB;
+        }
+        for (int ci0 = 0; ci0 < cin; ci0 += CB) {
+            float x[CB][KS];
+#pragma unroll
+            for (int u = 0; u < CB; ++u)
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+                    x[u][k] = bld1(rI, ci0 + u < cin ? toff[k] + (unsigned)((ci0 + u) * n_frames * 4) : SWN_OOB);
+#pragma unroll
+            for (int u = 0; u < CB; ++u) {
+                const int ci = ci0 + u < cin ? ci0 + u : cin - 1;          // past the end: x is zero, any valid weight will do
+#pragma unroll
+                for (int k = 0; k < KS; ++k)
+#pragma unroll
+                    for (int r = 0; r < CPT; ++r) {
+                        const int co = co0 + r;                            // wave-uniform -> scalar weight load
+                        const float wv = (co < cout) ? w[((size_t)co * cin + ci) * KS + k] : 0.f;
+                        acc[r] = fmaf(wv, x[u][k], acc[r]);
+                    }
             }
         }
+    };
+    if (ks == 1) run(std::integral_constant<int, 1>{});
+    else if (ks == 3) run(std::integral_constant<int, 3>{});
+    else {
+        const float* inb = in + (size_t)b * cin * n_frames;
+        for (int ci = 0; ci < cin; ++ci)
+            for (int k = 0; k < ks; ++k) {
+                const int ff = f + (k - half) * dil;
+                const float x = (f < n_frames && ff >= 0 && ff < n_frames) ? inb[(size_t)ci * n_frames + ff] : 0.f;
+#pragma unroll
+                for (int r = 0; r < CPT; ++r) {
+                    const int co = co0 + r;
+                    const float wv = (co < cout) ? w[((size_t)co * cin + ci) * ks + k] : 0.f;
+                    acc[r] = fmaf(wv, x, acc[r]);
+                }
+            }
     }
     if (f < n_frames) {
 #pragma unroll
