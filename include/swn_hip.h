@@ -153,11 +153,12 @@ int    swn_forward_bf16(const swn_net_desc* d, const float* packed_dev, const vo
 
 /* mixed-precision training: expand what swn_forward_bf16 kept in work_dev (bf16, time-major) into the fp32 work layout
  * of swn_forward (hidden states | relu(skip) | relu(out_1); swn_forward_work_floats() floats), so that swn_backward can
- * follow a bf16 forward of the same (cond, audio).  GEMM-stack class only; the BL6 class returns SWN_E_UNSUPPORTED
- * (its head kernel keeps the intermediate activations on chip) - use swn_forward there. */
-int    swn_bf16_train_forward_supported(const swn_net_desc* d);      /* 1 / 0 */
-int    swn_bf16_work_to_f32(const swn_net_desc* d, const void* work_bf16_dev, int batch, int n_frames,
-                            float* fwd_work_dev, void* stream);
+ * follow a bf16 forward of the same (cond, audio).  GEMM-stack class: all three are expanded from memory.  BL6 class:
+ * the head kernel keeps the two activations on chip, so the hidden states are expanded and the two 1x1 products are
+ * redone in fp32 from them (packed_dev is read only there).  _supported: 1 where swn_forward_bf16 exists, else 0. */
+int    swn_bf16_train_forward_supported(const swn_net_desc* d);
+int    swn_bf16_work_to_f32(const swn_net_desc* d, const float* packed_dev, const void* work_bf16_dev, int batch,
+                            int n_frames, float* fwd_work_dev, void* stream);
 
 /* ---- Laplace output split  (cswnv_shift1.py:228-267) -----------------------------------
  * raw (B, n_out, Tp) from swn_forward  ->  time-major tensors the reference returns:

@@ -76,7 +76,7 @@ SIGNATURES = {
     "swn_backward_drop": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "swn_bf16_train_forward_supported": (c_int, [POINTER(NetDesc)]),
-    "swn_bf16_work_to_f32": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "swn_bf16_work_to_f32": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "swn_train_set_precision": (c_int, [c_int]),
     "swn_train_get_precision": (c_int, []),
     "swn_laplace_head_backward": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,

@@ -671,7 +671,8 @@ int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g);
 size_t swn_bf16g_weight_bytes(const SwnGeom& g);
 int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf, hipStream_t st);
 size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
-int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, hipStream_t st);
+int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, bool hs_only, hipStream_t st);
+int swn_stack_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st);
 int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const void* audio,
                       int batch, int n_frames, void* work, float* out, hipStream_t st);
 
@@ -767,22 +768,24 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
 }
 
 // After swn_forward_bf16: expand what the forward kept (bf16, time-major) into the fp32 work layout of swn_forward, so
-// that swn_backward can follow a bf16 forward (mixed-precision training).  GEMM-stack class only: the BL6-class head
-// kernel keeps relu(skip) / relu(out_1) on chip, they are not in memory to expand.
+// that swn_backward can follow a bf16 forward (mixed-precision training).  GEMM-stack class: hidden states, relu(skip)
+// and relu(out_1) are all in memory.  BL6 class: the fused head keeps the two activations on chip, so the hidden
+// states are expanded and the two 1x1 products are redone by the fp32 GEMM kernel (packed_dev needed only there).
 extern "C" int swn_bf16_train_forward_supported(const swn_net_desc* d) {
     SwnGeom g;
-    if (bf_geom(d, &g) == SWN_OK) return 0;
+    if (bf_geom(d, &g) == SWN_OK) return 1;
     return swn_bf16g_geom(d, &g) == SWN_OK ? 1 : 0;
 }
 
-extern "C" int swn_bf16_work_to_f32(const swn_net_desc* d, const void* work_bf16, int batch, int n_frames, float* fwd_work,
-                                    void* stream_) {
+extern "C" int swn_bf16_work_to_f32(const swn_net_desc* d, const float* packed, const void* work_bf16, int batch, int n_frames,
+                                    float* fwd_work, void* stream_) {
     SwnGeom g;
-    if (bf_geom(d, &g) == SWN_OK) return SWN_E_UNSUPPORTED;
-    const int rc = swn_bf16g_geom(d, &g);
-    if (rc < 0) return rc;
-    if (!work_bf16 || !fwd_work || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+    const bool small = bf_geom(d, &g) == SWN_OK;
+    if (!small) { const int rc = swn_bf16g_geom(d, &g); if (rc < 0) return rc; }
+    if (!work_bf16 || !fwd_work || (small && !packed) || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
     if (Tp < 1) return SWN_E_BADARG;
-    return swn_bf16g_expand(g, work_bf16, batch, Tp, fwd_work, (hipStream_t)stream_);
+    const int rc = swn_bf16g_expand(g, work_bf16, batch, Tp, fwd_work, small, (hipStream_t)stream_);
+    if (rc < 0 || !small) return rc;
+    return swn_stack_head_acts(g, packed, fwd_work, batch, Tp, (hipStream_t)stream_);
 }

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void bf16g_expand_kernel(const unsigned short*
 }
 
 // what swn_bf16g_forward left in `work` -> the fp32 work layout of swn_forward: hs | relu(skip) | relu(out_1)
-int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, hipStream_t st) {
+int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, bool hs_only, hipStream_t st) {
     auto r64 = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const unsigned short* hs = reinterpret_cast<const unsigned short*>(work);
     const size_t lstride = (size_t)batch * Tp * g.H;
@@ -344,6 +344,7 @@ int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, flo
     // hidden states: matrix z = l * B + b  ->  dst [b][l][H][Tp]
     hipLaunchKernelGGL(bf16g_expand_kernel, dim3(tx, (g.H + 63) / 64, (g.L + 1) * batch), dim3(256), 0, st,
                        hs, (size_t)Tp * g.H, g.H, (int)Tp, fwd_work, batch, (size_t)(g.L + 1) * g.H * Tp, (size_t)g.H * Tp);
+    if (hs_only) return swn_launch_status("swn_bf16_work_to_f32");
     hipLaunchKernelGGL(bf16g_expand_kernel, dim3(tx, (g.S + 63) / 64, batch), dim3(256), 0, st,
                        skipb, (size_t)Tp * g.S, g.S, (int)Tp, s1, batch, (size_t)g.S * Tp, (size_t)0);
     hipLaunchKernelGGL(bf16g_expand_kernel, dim3(tx, (g.O1 + 63) / 64, batch), dim3(256), 0, st,

@@ -249,8 +249,8 @@ class HipNet:
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
 
     def _bf16_train_forward(self, cond, audio, B, Tf, work):
-        """mixed-precision mode, GEMM-stack geometries: bf16 forward, then its bf16 activations expanded into the fp32
-        buffers swn_backward reads.  Returns None (caller runs the fp32 forward) where the library has no such path.
+        """mixed-precision mode: bf16 forward, then its bf16 activations expanded into the fp32 buffers swn_backward
+        reads.  Returns None (caller runs the fp32 forward) where the library has no bf16 stack for the geometry.
         The bf16 copy of the weights is refreshed on every call: the parameters move between training steps."""
         L = self.lib
         d = ctypes.byref(self.desc)
@@ -268,7 +268,7 @@ class HipNet:
             _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), st), "pack_bf16")
             _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
                                           _ptr(wb), _ptr(out), st), "forward_bf16")
-            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(wb), B, Tf, _ptr(work), st), "bf16_work_to_f32")
+            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), st), "bf16_work_to_f32")
         return out
 
     def _drop_args(self, drop):

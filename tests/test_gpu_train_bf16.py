@@ -2,7 +2,8 @@
 accumulation) against the exact-fp32 mode of the same kernels and against the reference's own gradients.
 
 Tolerance (bf16 has 8 mantissa bits; products are summed in fp32): per parameter tensor
-||g_bf16 - g_ref||_2 <= 2e-2 * ||g_ref||_2 + 1e-6, and the loss itself is untouched (the forward stays fp32)."""
+||g_bf16 - g_ref||_2 <= 2e-2 * ||g_ref||_2 + 1e-6, where a bf16 stack exists for the geometry (BL6 class, H % 64 == 0) the forward of the step is bf16 as well
+(5e-2 there); elsewhere the forward stays fp32 and the loss is untouched."""
 import numpy as np
 import pytest
 import torch
@@ -109,16 +110,20 @@ def test_full_size_gradients_bf16_mode(gpu_ok, shape):
             loss = mc.LaplaceLoss()(res[0].reshape(B, Tp), res[1].reshape(B, Tp), tgt, log_b=res[2].reshape(B, Tp), log=False)
             loss.backward()
         out[mode] = _grads(m)
-    # at the run.sh geometry the forward runs on the bf16 GEMM stack as well (runtime._bf16_train_forward), so the
-    # gradients carry the rounding of both passes
-    _close(shape, out["bf16"], out["fp32"], tol=2e-2 if shape == "bl6" else 5e-2)
+    # the forward runs on the bf16 stack as well (runtime._bf16_train_forward), so the gradients carry the rounding of
+    # both passes
+    # (the floor covers the scalar upsampler bias, a sum of cancelling terms: 1e-3 of the largest tensor norm)
+    big = max(np.linalg.norm(v.ravel()) for v in out["fp32"].values())
+    _close(shape, out["bf16"], out["fp32"], tol=5e-2, floor=1e-3 * big)
 
 
-def test_bf16_forward_feeds_the_backward_at_the_gemm_stack_geometry(gpu_ok):
-    """mixed-precision mode at H % 64 == 0: swn_forward_bf16 + swn_bf16_work_to_f32 must leave in the fp32 work buffer
-    what swn_forward would have left (hidden states, relu(skip), relu(out_1)) up to bf16 rounding."""
+@pytest.mark.parametrize("shape", ["bl6", "ref6"])
+def test_bf16_forward_feeds_the_backward(gpu_ok, shape):
+    """mixed-precision mode where a bf16 stack exists: swn_forward_bf16 + swn_bf16_work_to_f32 must leave in the fp32
+    work buffer what swn_forward would have left (hidden states, relu(skip), relu(out_1)) up to bf16 rounding.  At the
+    BL6 class the two head activations are recomputed in fp32 from the expanded hidden states."""
     from shallow_wavenet_amd.runtime import HipNet
-    cfg = C.ref6_laplace(1, 4)
+    cfg = C.bl6_laplace(1, 0) if shape == "bl6" else C.ref6_laplace(1, 4)
     sd = synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True)
     net = HipNet.from_state_dict(cfg, sd, "cuda:0")
     B, Tf = 2, 9
@@ -135,11 +140,11 @@ def test_bf16_forward_feeds_the_backward_at_the_gemm_stack_geometry(gpu_ok):
     r64 = lambda x: (x + 63) & ~63
     n_hs, n_s1, n_r1 = B * (cfg.L + 1) * cfg.H * Tp, B * cfg.S * Tp, B * cfg.out1_chn * Tp
     o = 0
-    for n in (n_hs, n_s1, n_r1):          # the three sections of the work layout (the padding between them is never read)
+    for j, n in enumerate((n_hs, n_s1, n_r1)):    # the three sections of the work layout (the padding between them is never read)
         w32, w16 = s32["work"][o:o + n], s16["work"][o:o + n]
-        assert float((w16 - w32).abs().max()) <= 2e-2 * max(1.0, float(w32.abs().max()))
-        # every value the backward will read is a bf16 number
-        assert torch.equal(w16, w16.to(torch.bfloat16).to(torch.float32))
+        assert float((w16 - w32).abs().max()) <= 2e-2 * max(1.0, float(w32.abs().max())), (shape, j)
+        if j == 0 or shape == "ref6":             # expanded from bf16 storage: every value is a bf16 number
+            assert torch.equal(w16, w16.to(torch.bfloat16).to(torch.float32)), (shape, j)
         o += r64(n)
 
 
