@@ -193,8 +193,16 @@ def main():
                      "note": "latency-bound sequential chain; working set is L2/LDS/VGPR resident (SURVEY 7.3)"},
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        line["stack"] = stack_leg(cfg, net, dev)
-        line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        # auxiliary legs: a failure there must not cost the headline line
+        try:
+            line["stack"] = stack_leg(cfg, net, dev)
+        except Exception as e:                                  # noqa: BLE001
+            line["stack"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            line["cpu_baseline"] = cpu_baseline(cfg, sd)
+        except Exception as e:                                  # noqa: BLE001
+            line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+                                    "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
