@@ -77,7 +77,14 @@ template <bool XMUL>
 __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
     __shared__ float As[16][SWN_MMA_PITCH];
     __shared__ float Bs[16][SWN_MMA_PITCH];
-    const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    // XCD-aware order, as in time_gemm_bf16t_kernel: 1-D grid, each XCD walks a contiguous range of time tiles
+    const int ntt = (g.T + 63) / 64, mtl = (g.M + 63) / 64;
+    const int chunk = (ntt * g.nb + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ttl = idx / mtl, mtile = idx - ttl * mtl;
+    const int gt = xcd * chunk + ttl;
+    if (ttl >= chunk || gt >= ntt * g.nb) return;
+    const int b = gt / ntt, t0 = (gt - b * ntt) * 64, m0 = mtile * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const __amdgpu_buffer_rsrc_t rA = rsrc_of(g.A), rX = rsrc_of(g.X + (size_t)b * g.x_sb);
     const __amdgpu_buffer_rsrc_t rM = rsrc_of(XMUL ? g.xmul + (size_t)b * g.xm_sb : g.A);
@@ -346,11 +353,17 @@ struct ReduceGemm {
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
     __shared__ float Ps[16][SWN_MMA_PITCH];
     __shared__ float Qs[16][SWN_MMA_PITCH];
+    // XCD-aware order, as in reduce_gemm_bf16s_kernel: 1-D grid, the tiles of one time segment back to back on one XCD
     const int nseg = (g.T + g.TS - 1) / g.TS;
-    const int b = blockIdx.z / nseg, ts0 = (blockIdx.z - b * nseg) * g.TS;
-    const int m0 = blockIdx.x * 64, n0 = blockIdx.y * 64;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int Nc = g.taps * g.KC;
+    const int mtl = (g.M + 63) / 64, ntl = (Nc + 63) / 64, per_seg = mtl * ntl;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int sg = (idx / per_seg) * 8 + xcd, tile = idx - (idx / per_seg) * per_seg;
+    if (sg >= g.nsegtot) return;
+    const int b = sg / nseg, ts0 = (sg - b * nseg) * g.TS;
+    const int by = tile / mtl, bx = tile - by * mtl;
+    const int m0 = bx * 64, n0 = by * 64;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* Pb = g.P + (size_t)b * g.p_sb;
     const float* Qb = g.Q + (size_t)b * g.q_sb;
     swn_f32x4 acc[4] = {};
@@ -393,7 +406,7 @@ __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
         swn_mma_64x64x16(Ps, Qs, acc, lane, w);
         __syncthreads();
     }
-    if (g.gb && blockIdx.y == 0) {            // bias gradient: rows summed over the 16 time lanes of each group
+    if (g.gb && by == 0) {            // bias gradient: rows summed over the 16 time lanes of each group
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v = rs[i];
@@ -842,8 +855,11 @@ void launch_time(const TimeGemm& g, int B, hipStream_t st) {
         else hipLaunchKernelGGL(time_gemm_bf16_kernel<false>, grid, dim3(256), 0, st, g);
         return;
     }
-    if (g.xmul) { hipLaunchKernelGGL(time_gemm_kernel<true>, grid, dim3(256), 0, st, g); return; }
-    hipLaunchKernelGGL(time_gemm_kernel<false>, grid, dim3(256), 0, st, g);
+    TimeGemm h = g;
+    h.nb = B;
+    const dim3 lin((unsigned)(8 * ((grid.x * B + 7) / 8) * grid.y));
+    if (g.xmul) { hipLaunchKernelGGL(time_gemm_kernel<true>, lin, dim3(256), 0, st, h); return; }
+    hipLaunchKernelGGL(time_gemm_kernel<false>, lin, dim3(256), 0, st, h);
 }
 void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
     g.TS = 512;
@@ -869,7 +885,8 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
         else hipLaunchKernelGGL(reduce_gemm_bf16_kernel<false>, grid, dim3(256), 0, st, g);
         return;
     }
-    hipLaunchKernelGGL(reduce_gemm_kernel, grid, dim3(256), 0, st, g);
+    g.nsegtot = B * nseg;
+    hipLaunchKernelGGL(reduce_gemm_kernel, dim3((unsigned)(grid.x * grid.y * ((g.nsegtot + 7) / 8) * 8)), dim3(256), 0, st, g);
 }
 
 }  // namespace
