@@ -76,8 +76,17 @@ __global__ __launch_bounds__(256) void tf_layer_kernel(const FwdArgs a, const in
     __shared__ float Bs[16][SWN_MMA_PITCH];      // [k][position]
     const SwnGeom& g = a.g;
     const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg;
-    const int b = blockIdx.z;
-    const int t0 = blockIdx.x * 64, o0 = blockIdx.y * 32;
+    // XCD-aware order (1-D grid; workgroup id i runs on XCD i % 8): each XCD walks a contiguous range of time tiles, the
+    // channel tiles of one time tile back to back - they read the same window of h_{l-1}, and neighbouring time
+    // tiles share their tap halos in that XCD's L2
+    const int ntt = (a.Tp + 63) / 64, mtl = (H + 31) / 32;
+    const int chunk = (ntt * a.B + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ttl = idx / mtl, mtile = idx - ttl * mtl;
+    const int gt = xcd * chunk + ttl;
+    if (ttl >= chunk || gt >= ntt * a.B) return;
+    const int b = gt / ntt;
+    const int t0 = (gt - b * ntt) * 64, o0 = mtile * 32;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int dil = g.dil[l];
     const float* P = a.P;
@@ -341,7 +350,7 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         else hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a);
     }
     for (int l = 0; l < g.L; ++l) {
-        dim3 grid(tb64, (g.H + 31) / 32, batch);
+        const dim3 grid((unsigned)(8 * ((tb64 * batch + 7) / 8) * ((g.H + 31) / 32)));
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;      // layer l-1's output was dropped
         if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a, l, in_mul);
         else hipLaunchKernelGGL(tf_layer_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a, l, in_mul);
