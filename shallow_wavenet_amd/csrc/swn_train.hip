@@ -867,9 +867,12 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
     const dim3 grid((g.M + 63) / 64, (g.taps * g.KC + 63) / 64, B * nseg);
     if (g_train_bf16.load(std::memory_order_relaxed)) {
         if (!g.qmul && g.p_st == 1 && g.q_st == 1 && g.T >= 256) {
-            // 128 x 128 tiles; time segments sized so that about a thousand workgroups exist
+            // 128 x 128 tiles; time segments sized for a target number of workgroups
             const int mt = (g.M + 127) / 128, nt = (g.taps * g.KC + 127) / 128;
-            int want = (1024 + mt * nt * B - 1) / (mt * nt * B);
+            // (a single-tile gradient pays 16 K float atomics per workgroup for very little MFMA work: one workgroup per CU
+            //  there; with many tiles per segment the atomics amortise and more workgroups hide the loads - measured both ways)
+            const int target = mt * nt >= 4 ? 1024 : 256;
+            int want = (target + mt * nt * B - 1) / (mt * nt * B);
             const int most = (g.T + 255) / 256;
             if (want > most) want = most;
             if (want < 1) want = 1;
