@@ -155,7 +155,7 @@ int    swn_forward_bf16(const swn_net_desc* d, const float* packed_dev, const vo
  * of swn_forward (hidden states | relu(skip) | relu(out_1); swn_forward_work_floats() floats), so that swn_backward can
  * follow a bf16 forward of the same (cond, audio).  GEMM-stack class: all three are expanded from memory.  BL6 class:
  * the head kernel keeps the two activations on chip, so the hidden states are expanded and the two 1x1 products are
- * redone in fp32 from them (packed_dev is read only there).  _supported: 1 where swn_forward_bf16 exists, else 0. */
+ * redone from them in the arithmetic of swn_train_set_precision (packed_dev is read only there).  _supported: 1 where swn_forward_bf16 exists, else 0. */
 int    swn_bf16_train_forward_supported(const swn_net_desc* d);
 int    swn_bf16_work_to_f32(const swn_net_desc* d, const float* packed_dev, const void* work_bf16_dev, int batch,
                             int n_frames, float* fwd_work_dev, void* stream);

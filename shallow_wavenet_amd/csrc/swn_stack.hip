@@ -372,26 +372,6 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
 
 }  // namespace
 
-// relu(skip) and relu(out_1) from fp32 hidden states already in `work` (layout of swn_forward_work_floats): the tail of
-// forward_impl without out_2.  Used when the hidden states come from the BL6-class bf16 layer kernels, whose fused head
-// keeps these two activations on chip (swn_bf16_work_to_f32).
-int swn_stack_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st) {
-    if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
-    SwnLayout y; swn_make_layout(&g, &y);
-    const size_t hs_floats = r64((size_t)batch * (g.L + 1) * g.H * Tp);
-    float* skipb = work + hs_floats;
-    float* o1b = skipb + r64((size_t)batch * g.S * Tp);
-    const unsigned tb64 = (unsigned)((Tp + 63) / 64);
-    const size_t hstride = (size_t)(g.L + 1) * g.H * Tp;
-    hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.S + 63) / 64, batch), dim3(256), 0, st,
-                       packed + y.wsk, g.L * g.Hp, packed + y.bsk, work + (size_t)g.H * Tp, hstride,
-                       skipb, (size_t)g.S * Tp, g.S, g.L * g.H, (int)Tp, 1);
-    hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.O1 + 63) / 64, batch), dim3(256), 0, st,
-                       packed + y.w1, g.Sp, packed + y.b1, skipb, (size_t)g.S * Tp,
-                       o1b, (size_t)g.O1 * Tp, g.O1, g.S, (int)Tp, 1);
-    return swn_launch_status("swn_bf16_work_to_f32");
-}
-
 extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const float* cond, const void* audio,
                            int batch, int n_frames, float* work, float* out, float* hs, void* stream_) {
     return forward_impl(d, packed, cond, nullptr, audio, batch, n_frames, nullptr, nullptr, work, out, hs, stream_, "swn_forward");

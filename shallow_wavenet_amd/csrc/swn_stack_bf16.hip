@@ -672,7 +672,7 @@ size_t swn_bf16g_weight_bytes(const SwnGeom& g);
 int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf, hipStream_t st);
 size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
 int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, bool hs_only, hipStream_t st);
-int swn_stack_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st);
+int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st);
 int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const void* audio,
                       int batch, int n_frames, void* work, float* out, hipStream_t st);
 
@@ -770,7 +770,8 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
 // After swn_forward_bf16: expand what the forward kept (bf16, time-major) into the fp32 work layout of swn_forward, so
 // that swn_backward can follow a bf16 forward (mixed-precision training).  GEMM-stack class: hidden states, relu(skip)
 // and relu(out_1) are all in memory.  BL6 class: the fused head keeps the two activations on chip, so the hidden
-// states are expanded and the two 1x1 products are redone by the fp32 GEMM kernel (packed_dev needed only there).
+// states are expanded and the two 1x1 products are redone by the training contraction kernel, in the arithmetic mode
+// of swn_train_set_precision (packed_dev needed only there).
 extern "C" int swn_bf16_train_forward_supported(const swn_net_desc* d) {
     SwnGeom g;
     if (bf_geom(d, &g) == SWN_OK) return 1;
@@ -787,5 +788,5 @@ extern "C" int swn_bf16_work_to_f32(const swn_net_desc* d, const float* packed, 
     if (Tp < 1) return SWN_E_BADARG;
     const int rc = swn_bf16g_expand(g, work_bf16, batch, Tp, fwd_work, small, (hipStream_t)stream_);
     if (rc < 0 || !small) return rc;
-    return swn_stack_head_acts(g, packed, fwd_work, batch, Tp, (hipStream_t)stream_);
+    return swn_train_head_acts(g, packed, fwd_work, batch, Tp, (hipStream_t)stream_);
 }

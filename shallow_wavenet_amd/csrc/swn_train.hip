@@ -31,6 +31,7 @@ struct TimeGemm {
     const float* ymul; long ym_sb, ym_sm;           // the result is scaled by ymul[b][m][t] before it is stored / added
     int XT;                                         // X is valid on [0, XT) (0: same as T)
     int nb;                                         // batch size (set by the launcher of the XCD-ordered kernel)
+    const float* bias; int relu;                    // optional: v = acc + bias[m], then max(v, 0)  (forward 1x1 layers)
 };
 
 // Epilogue of the time contractions: relu mask, dropout multiplier, accumulate, store - for NV results of one thread.
@@ -42,6 +43,10 @@ __device__ __forceinline__ void tg_epilogue(const TimeGemm& g, const int b, cons
     bool ok[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) ok[i] = m[i] < g.M && t < g.T;
+    if (g.bias) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) { v[i] += g.bias[ok[i] ? m[i] : 0]; if (g.relu) v[i] = fmaxf(v[i], 0.f); }
+    }
     if (g.mask) {
         const __amdgpu_buffer_rsrc_t r = rsrc_of(g.mask + (size_t)b * g.k_sb);
         float k[NV];
@@ -938,6 +943,30 @@ __global__ __launch_bounds__(256) void xm_bwd_kernel(const float* __restrict__ d
 }
 
 }  // namespace
+
+// relu(skip) and relu(out_1) from fp32 hidden states already in `work` (layout of swn_forward_work_floats) through the
+// contraction kernels of this file, i.e. in the arithmetic mode of swn_train_set_precision: the tail of the training
+// forward when the hidden states come from the BL6-class bf16 layer kernels (swn_bf16_work_to_f32).
+int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int B, long Tp, hipStream_t st) {
+    if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
+    SwnLayout y; swn_make_layout(&g, &y);
+    float* skipb = work + r64((size_t)B * (g.L + 1) * g.H * Tp);
+    float* o1b = skipb + r64((size_t)B * g.S * Tp);
+    (void)hipGetLastError();
+    {   // skip[b][c][t] = relu(bsk[c] + sum_{l,i} Wsk[c][l*H+i] h_{l+1}[b][i][t])
+        TimeGemm t = {packed + y.wsk, (long)g.L * g.Hp, 0, 1, work + (size_t)g.H * Tp, (long)(g.L + 1) * g.H * Tp, Tp, 1,
+                      skipb, (long)g.S * Tp, Tp, nullptr, 0, 0, g.S, 1, g.L * g.H, (int)Tp, 1, 0, 1, 0};
+        t.bias = packed + y.bsk; t.relu = 1;
+        launch_time(t, B, st);
+    }
+    {   // o1 = relu(b1 + W1 skip)
+        TimeGemm t = {packed + y.w1, g.Sp, 0, 1, skipb, (long)g.S * Tp, Tp, 1, o1b, (long)g.O1 * Tp, Tp, nullptr, 0, 0,
+                      g.O1, 1, g.S, (int)Tp, 1, 0, 1, 0};
+        t.bias = packed + y.b1; t.relu = 1;
+        launch_time(t, B, st);
+    }
+    return swn_launch_status("swn_bf16_work_to_f32");
+}
 
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
                           int B, int Tx, int Tp, hipStream_t st) {
