@@ -4,7 +4,8 @@ oracle differentiated by torch autograd on the same inputs (oracle/cpu_ref.py re
 pinned to the reference by the g0_* gradient fixtures at sizes the reference finishes in seconds).
 
 Tolerances: head outputs <= 1e-5 abs (north_star), loss <= 1e-5 relative; gradients are sums over 132 000 positions
-accumulated in a different order (tiles, float atomics): per tensor ||g - g_ref||_2 <= 1e-3 ||g_ref||_2 + 1e-6."""
+accumulated in a different order (tiles, float atomics): per tensor ||g - g_ref||_2 <= 1e-3 ||g_ref||_2 + 1e-6.
+The mixed-precision mode of the same step is checked against the same oracle gradients at 5e-2."""
 import numpy as np
 import pytest
 import torch
@@ -55,3 +56,20 @@ def test_cfg4_forward_loss_and_gradients_match_the_oracle(gpu_ok):
         assert err <= 1e-3 * np.linalg.norm(r) + 1e-6, (k, err, np.linalg.norm(r))
         seen += 1
     assert seen == len(P)
+
+    # the same step in the mixed-precision mode (bf16 forward feeding the backward, bf16 operands in the contractions):
+    # outputs within 5e-3 of the fp32 ones, gradients within 5e-2 (tensor norm; floor for the cancelling scalar bias)
+    from shallow_wavenet_amd.runtime import train_precision
+    for p in m.parameters():
+        p.grad = None
+    with train_precision("bf16"):
+        mu16, b16, logb16 = m(aux.cuda(), audio.cuda())
+        loss16 = mc.LaplaceLoss()(mu16, b16, tgt.cuda(), log_b=logb16, log=False)
+        loss16.backward()
+    assert float((mu16.cpu() - mu_r.detach()).abs().max()) <= 5e-3 * max(1.0, float(mu_r.abs().max()))
+    assert abs(loss16.item() - loss_r.item()) <= 2e-3 * max(1.0, abs(loss_r.item()))
+    big = max(float(np.linalg.norm(P[k].grad.numpy().ravel())) for k, _ in m.named_parameters())
+    for k, p in m.named_parameters():
+        g, r = p.grad.double().cpu().numpy().ravel(), P[k].grad.double().numpy().ravel()
+        err = np.linalg.norm(g - r)
+        assert err <= 5e-2 * np.linalg.norm(r) + 1e-3 * big, (k, err, np.linalg.norm(r))
