@@ -173,3 +173,31 @@ def test_dropout_gradients_bf16_mode(gpu_ok, name):
     # forward AND backward rounded: the smallest tensors (norm 5e-3) sit at 3-5 %; the floor covers the scalar
     # upsampler bias, a sum of cancelling terms of magnitude 2e-4
     _close(name, got, ref, tol=6e-2, floor=5e-5)
+
+
+def test_softmax_run_sh_geometry_bf16_mode(gpu_ok):
+    """DSWNV at the run.sh softmax geometry (H = 256, GEMM-stack class: int32 class indices through the bf16 forward,
+    logits and cross-entropy gradients): mixed-precision mode against the fp32 mode of the same kernels."""
+    cfg = C.ref6_softmax()
+    B, Tf = 2, 10
+    m = md.DSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=5, flavor="trained", identity_scale_in=True).items()})
+    m.cuda().train()
+    T = Tf * cfg.U
+    idx = torch.randint(0, cfg.n_quantize, (B, T - 1), generator=torch.Generator().manual_seed(1)).cuda()
+    tgt = torch.randint(0, cfg.n_quantize, (B, T - 1), generator=torch.Generator().manual_seed(2)).cuda()
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    out, lg = {}, {}
+    for mode in ("fp32", "bf16"):
+        for p in m.parameters():
+            p.grad = None
+        with train_precision(mode):
+            logits = m(md.OneHot(idx, cfg.n_quantize).transpose(1, 2), aux)
+            loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tgt.reshape(-1))
+            loss.backward()
+        out[mode], lg[mode] = _grads(m), logits.detach()
+    assert float((lg["bf16"] - lg["fp32"]).abs().max()) <= 2e-2 * max(1.0, float(lg["fp32"].abs().max()))
+    assert float((lg["bf16"] - lg["fp32"]).abs().max()) > 0
+    big = max(np.linalg.norm(v.ravel()) for v in out["fp32"].values())
+    # nine layers deep, both passes rounded, random labels: the frame-rate front end (norm 7e-3 of 0.02) sits at 5-6 %
+    _close("ref6_softmax", out["bf16"], out["fp32"], tol=1e-1, floor=1e-3 * big)
