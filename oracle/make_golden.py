@@ -18,6 +18,7 @@ Usage:  python oracle/make_golden.py [--only NAME_SUBSTR] [--skip-big]
 from __future__ import annotations
 
 import argparse
+import dataclasses
 import hashlib
 import os
 import sys
@@ -213,7 +214,7 @@ def gen_softmax(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, head_str
           f"min margin={margin.min():.2e}")
 
 
-def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p):
+def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p, do=True):
     """training-mode forward + backward WITH dropout (model.train(), do=True, do_prob=p): the masks the reference
     draws are re-derived with shallow_wavenet_amd.noise.dropout_masks from the same seed and checked through the
     oracle against the reference's own outputs before anything is stored."""
@@ -228,14 +229,14 @@ def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p):
     B, T = len(frames), max(frames) * cfg.U
     rng = np.random.Generator(np.random.PCG64([aux_seed, 9]))
     out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, flavor=np.array(flavor), frames=np.array(frames),
-               aux=aux, drop_seed=drop_seed, drop_p=np.float64(p))
+               aux=aux, drop_seed=drop_seed, drop_p=np.float64(p), do=np.int64(1 if do else 0))
     P = cpu_ref.as_params(sd)
     if cfg.kind == "laplace":
         audio = rng.uniform(-0.9, 0.9, size=(B, 1, T - cfg.seg)).astype(np.float32)
         torch.manual_seed(drop_seed)
-        res = m(torch.from_numpy(aux), torch.from_numpy(audio), do=True, clip=False)
+        res = m(torch.from_numpy(aux), torch.from_numpy(audio), do=do, clip=False)
         torch.manual_seed(drop_seed)
-        drop = swn_noise.dropout_masks(cfg, B, max(frames), p)
+        drop = swn_noise.dropout_masks(cfg, B, max(frames), p, draw_x=do)
         raw, _ = cpu_ref.laplace_stack(cfg, P, torch.from_numpy(aux), torch.from_numpy(audio), drop=drop)
         mu_o = raw.transpose(1, 2)[:, :, :cfg.seg].reshape(res[0].shape)
         err = (mu_o - res[0].detach()).abs().max().item()
@@ -440,6 +441,13 @@ def main():
     jobs.append(("g5_drop_tiny_lap_c2d_s2l4", gen_dropout,
                  dict(cfg=C.tiny("laplace", 2, 4, aux_conv2d_flag=True), frames=[6, 6], wseed=33, flavor="xavier",
                       aux_seed=3, drop_seed=43, p=0.3)))
+    # <=2-layer Laplace stack: layer 0 always goes through dcrnn_drop in training mode, with and without do (cswnv_shift1.py:220-223)
+    two = dataclasses.replace(C.tiny("laplace", 1, 0), dilation_depth=2, dilation_repeat=1)
+    jobs.append(("g5_drop_two_lap_do", gen_dropout,
+                 dict(cfg=two, frames=[6, 5], wseed=35, flavor="xavier", aux_seed=3, drop_seed=45, p=0.5)))
+    jobs.append(("g5_drop_two_lap_nodo", gen_dropout,
+                 dict(cfg=dataclasses.replace(C.tiny("laplace", 2, 4), dilation_depth=1, dilation_repeat=2), frames=[6, 5],
+                      wseed=36, flavor="xavier", aux_seed=3, drop_seed=46, p=0.4, do=False)))
     jobs.append(("g5_drop_tiny_softmax", gen_dropout,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[6, 5], wseed=34, flavor="xavier", aux_seed=3,
                       drop_seed=44, p=0.5)))

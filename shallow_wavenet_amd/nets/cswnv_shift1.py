@@ -109,10 +109,11 @@ class CSWNV(EngineMixin, nn.Module):
         # nn.Dropout only acts in training mode (model.train(), train_cswnv...py:716); masks are drawn on the host
         # in the reference's order and handed to the dropout-mode kernels
         drop = None
-        if do and self.do_prob > 0 and self.training:
-            if self.dilation_depth * self.dilation_repeat <= 2:
-                raise NotImplementedError("dropout for a <=2-layer stack (cswnv_shift1.py:221-223) is not built")
-            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob)
+        # a <=2-layer stack sends layer 0 through dcrnn_drop whatever `do` says (cswnv_shift1.py:220-223); aux_drop
+        # still follows `do`
+        two = self.dilation_depth * self.dilation_repeat <= 2
+        if self.do_prob > 0 and self.training and (do or two):
+            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob, draw_x=bool(do))
         if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
             # training: HIP forward + HIP backward behind autograd Functions (nets/_autograd.py)
             from shallow_wavenet_amd.nets._autograd import LaplaceHeadFunction, StackFunction

@@ -160,7 +160,8 @@ def test_dropout_gradients_bf16_mode(gpu_ok, name):
     tgt = torch.from_numpy(d["loss_target"]).cuda()
     with train_precision("bf16"):
         torch.manual_seed(int(d["drop_seed"]))
-        res = m(torch.from_numpy(d["aux"]).cuda(), torch.from_numpy(d["fwd_audio"]).cuda(), do=True, clip=False)
+        do = bool(int(d["do"])) if "do" in d else True
+        res = m(torch.from_numpy(d["aux"]).cuda(), torch.from_numpy(d["fwd_audio"]).cuda(), do=do, clip=False)
         for i, r in enumerate(res):
             assert np.abs(r.detach().cpu().numpy() - d[f"fwd_{i}"]).max() <= 2e-2, (name, i)
         loss = mc.LaplaceLoss()(res[0], res[1], tgt, log_b=res[2], log=False)

@@ -193,10 +193,11 @@ def test_dropout_masks_and_oracle_reproduce_the_reference_training_forward(name)
     P = _params(cfg, d)
     B, Tf = d["aux"].shape[0], d["aux"].shape[2]
     torch.manual_seed(int(d["drop_seed"]))
-    drop = swn_noise.dropout_masks(cfg, B, Tf, float(d["drop_p"]))
+    do = bool(int(d["do"])) if "do" in d else True
+    drop = swn_noise.dropout_masks(cfg, B, Tf, float(d["drop_p"]), draw_x=do)
     keep = 1.0 - float(d["drop_p"])
     vals = set(np.unique(drop[0].numpy()).tolist())
-    assert vals <= {0.0, np.float32(1.0 / keep).item()}
+    assert vals <= ({0.0, np.float32(1.0 / keep).item()} if do else {1.0})
     assert [m is not None for m in drop[1]] == [l in swn_noise.dropped_layers(cfg) and l + 1 < cfg.L for l in range(cfg.L)]
     if cfg.kind == "laplace":
         raw, _ = cpu_ref.laplace_stack(cfg, P, torch.from_numpy(d["aux"]), torch.from_numpy(d["fwd_audio"]), drop=drop)
