@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
     int ftap = 0, fc0 = 0;                                     // (tap, channel base) of the next tile to fetch: scalars
     float ra[2][16], rb[2][16];
     auto fetch = [&](float (&qa)[16], float (&qb)[16]) {
-        const bool live = ftap < g.taps;
+        const bool live = fc0 < g.KC;
         const int ts = t0 + tb + g.sgn * (ftap - g.center) * g.dil;
         const unsigned xb = (live && tok && ts >= 0 && ts < XT) ? (unsigned)(ts * 4) + (unsigned)fc0 * xs4 : SWN_OOB;
 #pragma unroll
@@ -286,8 +286,12 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
                 for (int e = 0; e < 4; ++e) qa[4 * i + e] = bld1(rA, arow[i] + sA + (unsigned)e * as4);
             }
         }
-        fc0 += 32;
-        if (fc0 >= g.KC) { fc0 = 0; ++ftap; }
+        // taps innermost: the K windows of one channel chunk overlap (shift dil < tile width) and are read back to back,
+        // and neighbouring time tiles walk the chunks in step, so a chunk's halo is shared in L2 while it is hot
+        // (taps outermost put 12 k-tiles between two reads of the same bytes: 1.29 GB fetched per data-gradient launch at the
+        //  run.sh geometry against 0.38 GB in this order, FETCH_SIZE; the launch itself gained 1 % - the Infinity Cache had
+        //  been absorbing the re-reads)
+        if (++ftap >= g.taps) { ftap = 0; fc0 += 32; }
     };
     auto stage = [&](const float (&qa)[16], const float (&qb)[16]) {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
