@@ -359,6 +359,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--verbose", default=1, type=int)
     p.add_argument("--synthetic", default=0, type=int, help="train on N generated utterances (no files needed)")
     p.add_argument("--max_iters", default=0, type=int, help="stop after this many chunks (0 = run all epochs)")
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                   help="arithmetic of the training step's contractions (not a reference flag): fp32 = parity mode, "
+                        "bf16 = bf16 operands with fp32 accumulation (swn_train_set_precision)")
     return p
 
 
@@ -389,6 +392,10 @@ def main(argv=None) -> int:
     if not torch.cuda.is_available():
         logging.error("gpu is not available. please check the setting.")
         return 1
+    if args.precision != "fp32":
+        from shallow_wavenet_amd.runtime import train_precision
+        train_precision(args.precision)          # process-wide, for the whole run
+        logging.info("training contractions in %s operands, fp32 accumulation" % args.precision)
     from shallow_wavenet_amd.nets.cswnv_shift1 import CSWNV, LaplaceLoss, LSDloss, initialize
     model = CSWNV(n_aux=args.n_aux, skip_chn=args.skip_chn, hid_chn=args.hid_chn, dilation_depth=args.dilation_depth,
                   dilation_repeat=args.dilation_repeat, kernel_size=args.kernel_size,

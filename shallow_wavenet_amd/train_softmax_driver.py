@@ -125,6 +125,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--verbose", default=1, type=int)
     p.add_argument("--synthetic", default=0, type=int)
     p.add_argument("--max_iters", default=0, type=int)
+    p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                   help="arithmetic of the training step's contractions (not a reference flag): fp32 = parity mode, "
+                        "bf16 = bf16 operands with fp32 accumulation (swn_train_set_precision)")
     return p
 
 
@@ -144,6 +147,10 @@ def main(argv=None) -> int:
     if not torch.cuda.is_available():
         logging.error("gpu is not available. please check the setting.")
         return 1
+    if args.precision != "fp32":
+        from shallow_wavenet_amd.runtime import train_precision
+        train_precision(args.precision)          # process-wide, for the whole run
+        logging.info("training contractions in %s operands, fp32 accumulation" % args.precision)
     from .nets.dswnv import DSWNV, initialize
     model = DSWNV(n_quantize=args.n_quantize, n_aux=args.n_aux, hid_chn=args.hid_chn, skip_chn=args.skip_chn,
                   dilation_depth=args.dilation_depth, dilation_repeat=args.dilation_repeat, kernel_size=args.kernel_size,

@@ -84,6 +84,11 @@ def test_cli_flags_are_the_reference_flags():
     assert want <= have
     ns = T.build_parser().parse_args(["--expdir", "x", "--aux_conv2d_flag", "true", "--wav_conv_flag", "false"])
     assert ns.aux_conv2d_flag is True and ns.wav_conv_flag is False and ns.lr == 1e-4 and ns.batch_size == 8800
+    # not a reference flag: arithmetic of the training contractions, parity mode unless asked otherwise
+    assert ns.precision == "fp32"
+    assert T.build_parser().parse_args(["--expdir", "x", "--precision", "bf16"]).precision == "bf16"
+    with pytest.raises(SystemExit):
+        T.build_parser().parse_args(["--expdir", "x", "--precision", "fp8"])
 
 
 def test_softmax_driver_chunk_plan_and_flags():
@@ -98,6 +103,7 @@ def test_softmax_driver_chunk_plan_and_flags():
     assert S.chunk_plan(2, rf, bs, U) == []                     # 220 samples <= rf + 1: nothing to train on
     have = {a.dest for a in S.build_parser()._actions}
     assert {"n_quantize", "audio_in", "wav_conv_flag", "do_prob", "batch_size", "epoch_count", "stats", "resume"} <= have
+    assert "precision" in have
     x = torch.arange(700)
     h = torch.zeros(40, 3)
     bh, bx, trg = S.slice_chunk(x, h, 17, 340, 14, 280)
