@@ -78,3 +78,25 @@ def test_softmax_training_chunk_matches_reference_module(gpu_ok):
             p.grad = torch.zeros_like(p)
     _check(name, m, d)
     opt.step()
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_stage4_driver_runs_a_few_chunks_on_synthetic_data(gpu_ok, tmp_path, caplog, precision):
+    """the stage-4 driver end to end (chunk generator, dropout masks, HIP forward/backward behind autograd, NLL + STFT
+    losses, Adam, log lines) on generated utterances, in the parity mode and in the mixed-precision mode."""
+    from shallow_wavenet_amd.runtime import train_precision
+    import logging
+    exp = tmp_path / precision
+    caplog.set_level(logging.INFO)
+    try:
+        rc = T.main(["--expdir", str(exp), "--synthetic", "3", "--max_iters", "4", "--n_aux", "10", "--hid_chn", "32",
+                     "--skip_chn", "48", "--dilation_depth", "3", "--dilation_repeat", "2", "--kernel_size", "3",
+                     "--upsampling_factor", "20", "--seg", "1", "--lpc", "0", "--batch_size", "600", "--n_fft_facts", "5",
+                     "--do_prob", "0.5", "--wav_conv_flag", "true", "--epoch_count", "1", "--verbose", "1",
+                     "--precision", precision])
+    finally:
+        train_precision("fp32")            # the switch is process-wide: leave the parity mode on for the other tests
+    assert rc == 0
+    assert (exp / "model.conf").exists()
+    text = caplog.text.lower()              # the driver's per-chunk loss lines (pytest owns the root logger, no file)
+    assert "iteration" in text and "nan" not in text
