@@ -100,3 +100,24 @@ def test_stage4_driver_runs_a_few_chunks_on_synthetic_data(gpu_ok, tmp_path, cap
     assert (exp / "model.conf").exists()
     text = caplog.text.lower()              # the driver's per-chunk loss lines (pytest owns the root logger, no file)
     assert "iteration" in text and "nan" not in text
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_stage7_softmax_driver_runs_a_few_chunks_on_synthetic_data(gpu_ok, tmp_path, caplog, precision):
+    """the softmax (DSWNV) driver end to end on generated utterances: chunk plan, mu-law classes, one-hot input, HIP
+    forward/backward, cross entropy past the receptive field, Adam - both arithmetic modes."""
+    import logging
+    from shallow_wavenet_amd import train_softmax_driver as S
+    from shallow_wavenet_amd.runtime import train_precision
+    exp = tmp_path / precision
+    caplog.set_level(logging.INFO)
+    try:
+        rc = S.main(["--expdir", str(exp), "--synthetic", "3", "--max_iters", "4", "--n_aux", "10", "--hid_chn", "32",
+                     "--skip_chn", "48", "--dilation_depth", "3", "--dilation_repeat", "2", "--kernel_size", "3",
+                     "--upsampling_factor", "20", "--batch_size", "400", "--do_prob", "0.5", "--epoch_count", "1",
+                     "--verbose", "1", "--precision", precision])
+    finally:
+        train_precision("fp32")
+    assert rc == 0
+    text = caplog.text.lower()
+    assert "nan" not in text
