@@ -30,7 +30,7 @@ from typing import Iterator, List, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import dist as D
+from . import artefacts, dist as D
 from .nets import cswnv_shift1 as laplace_mod
 from .nets import dswnv as softmax_mod
 from .runtime import HipNet, pack_state_dict
@@ -81,6 +81,8 @@ def pad_list(batch_list: Sequence[np.ndarray], pad_value: float = 0.0) -> np.nda
 
 def plan_batches(feat_list: Sequence[str], frames: Sequence[int], batch_size: int) -> List[List[str]]:
     """sort by frame count (np.argsort like the reference) and cut into ceil(N/bs) near-equal batches."""
+    if len(feat_list) == 0:          # a rank with an empty shard (fewer utterances than GPUs) decodes nothing
+        return []
     idx = np.argsort(list(frames))
     ordered = [feat_list[i] for i in idx]
     n_batch = math.ceil(len(ordered) / batch_size)
@@ -108,12 +110,9 @@ def write_wav_pcm16(path: str, samples: np.ndarray, fs: int) -> None:
 
 
 def load_config(path: str):
-    """model.conf: the pickled argparse Namespace the training script wrote (train_cswnv...py:293),
-    or the same fields as JSON."""
-    if path.endswith(".json"):
-        with open(path) as f:
-            return SimpleNamespace(**json.load(f))
-    return torch.load(path, weights_only=False)      # file written by this pipeline's own training stage
+    """model.conf: the pickled argparse Namespace the training stage wrote (train_cswnv...py:293; ours or the
+    reference's), a dict of the same fields, or JSON - loaded without executing anything (artefacts.py)."""
+    return artefacts.load_config(path)
 
 
 # --------------------------------------------------------------------------- model construction
@@ -141,7 +140,7 @@ def gpu_decode(kind: str, args, config, feat_list: Sequence[str], device, packed
         rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
         cfg = model._cfg
         if rank == packed_src_rank:
-            sd = torch.load(args.checkpoint, map_location="cpu", weights_only=True)["model"]
+            sd = artefacts.load_checkpoint(args.checkpoint)["model"]       # per-epoch or final file (run.sh:658)
             model.load_state_dict(sd)
             packed = pack_state_dict(cfg, model.state_dict())
         else:

@@ -25,6 +25,8 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from . import artefacts
+
 FFT_FACTS = {5: [128, 256, 512, 1024, 2048],
              9: [128, 192, 256, 384, 512, 768, 1024, 1536, 2048],
              17: [128, 160, 192, 224, 256, 320, 384, 448, 512, 640, 768, 896, 1024, 1280, 1536, 1792, 2048]}
@@ -298,12 +300,8 @@ def set_scale_in(model, mean: np.ndarray, scale: np.ndarray) -> None:
 
 
 def save_checkpoint(checkpoint_dir: str, model, optimizer, numpy_random_state, torch_random_state, iterations: int):
-    """same dictionary as the reference (train_cswnv...py:162-182); tensors are saved on the CPU."""
-    os.makedirs(checkpoint_dir, exist_ok=True)
-    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    torch.save({"model": sd, "optimizer": optimizer.state_dict(), "numpy_random_state": numpy_random_state,
-                "torch_random_state": torch_random_state, "iterations": iterations},
-               os.path.join(checkpoint_dir, "checkpoint-%d.pkl" % iterations))
+    """same dictionary as the reference (train_cswnv...py:162-182), loadable with weights_only=True (artefacts.py)."""
+    artefacts.save_checkpoint(checkpoint_dir, model, optimizer, numpy_random_state, torch_random_state, iterations)
     logging.info("%d-iter checkpoint created." % iterations)
 
 
@@ -388,7 +386,7 @@ def main(argv=None) -> int:
     os.environ["PYTHONHASHSEED"] = str(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    torch.save(vars(args), os.path.join(args.expdir, "model.conf"))
+    artefacts.save_config(args, os.path.join(args.expdir, "model.conf"))      # the Namespace, train_cswnv...py:293
     if not torch.cuda.is_available():
         logging.error("gpu is not available. please check the setting.")
         return 1
@@ -426,11 +424,11 @@ def main(argv=None) -> int:
     epoch_idx = 0
     checkpoint = None
     if args.pretrained is not None:
-        checkpoint = torch.load(args.pretrained, weights_only=True)
+        checkpoint = artefacts.load_checkpoint(args.pretrained)
         model.load_state_dict(checkpoint["model"])
         logging.info("pretrained from %d-iter checkpoint." % checkpoint["iterations"])
     elif args.resume is not None:
-        checkpoint = torch.load(args.resume, weights_only=False)      # our own file: holds the numpy RNG state
+        checkpoint = artefacts.load_checkpoint(args.resume)
         model.load_state_dict(checkpoint["model"])
         optimizer.load_state_dict(checkpoint["optimizer"])
         epoch_idx = checkpoint["iterations"]

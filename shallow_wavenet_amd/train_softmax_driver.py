@@ -18,6 +18,7 @@ from typing import List, Tuple
 import numpy as np
 import torch
 
+from . import artefacts
 from .train_driver import (_file_lists, read_feat, read_stats, read_wav, save_checkpoint, set_scale_in,
                            synthetic_corpus, validate_length)
 
@@ -143,7 +144,7 @@ def main(argv=None) -> int:
     os.environ["PYTHONHASHSEED"] = str(args.seed)
     np.random.seed(args.seed)
     torch.manual_seed(args.seed)
-    torch.save(vars(args), os.path.join(args.expdir, "model.conf"))
+    artefacts.save_config(args, os.path.join(args.expdir, "model.conf"))      # the Namespace, train_dswnv_softmax.py
     if not torch.cuda.is_available():
         logging.error("gpu is not available. please check the setting.")
         return 1
@@ -178,11 +179,11 @@ def main(argv=None) -> int:
     optimizer = torch.optim.Adam(optimizer_parameters(model), lr=args.lr)
     epoch_idx, checkpoint = 0, None
     if args.pretrained is not None:
-        checkpoint = torch.load(args.pretrained, weights_only=True)
+        checkpoint = artefacts.load_checkpoint(args.pretrained)
         model.load_state_dict(checkpoint["model"])
         logging.info("pretrained from %d-iter checkpoint." % checkpoint["iterations"])
     elif args.resume is not None:
-        checkpoint = torch.load(args.resume, weights_only=False)      # our own file: holds the numpy RNG state
+        checkpoint = artefacts.load_checkpoint(args.resume)
         model.load_state_dict(checkpoint["model"])
         optimizer.load_state_dict(checkpoint["optimizer"])
         epoch_idx = checkpoint["iterations"]

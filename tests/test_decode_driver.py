@@ -92,7 +92,7 @@ def test_driver_end_to_end_reproduces_the_reference_batch(gpu_ok, tmp_path, name
     feats, names = _write_run(tmp_path, cfg, d, kind)
     out = tmp_path / "wav"
     script = os.path.join(ROOT, "shallow_wavenet_amd", "bin",
-                          "decode_cswnv_laplace_shift1.py" if kind == "laplace" else "decode_dswnv_softmax.py")
+                          "decode_cswnv_laplace-shift1.py" if kind == "laplace" else "decode_dswnv_softmax.py")
     r = subprocess.run([sys.executable, script, "--feats", str(feats), "--checkpoint", str(tmp_path / "checkpoint-1.pkl"),
                         "--config", str(tmp_path / "model.json"), "--outdir", str(out), "--fs", "22050",
                         "--batch_size", "2", "--seed", str(int(d["noise_seed"])), "--verbose", "1"],

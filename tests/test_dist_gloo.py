@@ -60,3 +60,34 @@ def test_shard_matches_numpy_array_split():
     for n in (1, 2, 3, 8):
         want = [a.tolist() for a in np.array_split(items, n)]
         assert D.shard_utterances(items, n) == want
+
+
+def _worker_sparse(rank, world, port, q):
+    """more ranks than utterances: the spare rank joins the broadcast and the barrier with an empty shard."""
+    from shallow_wavenet_amd import decode_driver as DD
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w, _ = D.init_from_env(backend="gloo")
+    cfg = C.tiny("laplace", 1, 0)
+    packed = pack_state_dict(cfg, synth_state_dict(cfg, seed=9)) if r == 0 else None
+    buf = D.broadcast_packed(cfg, packed, "cpu")
+    mine = D.shard_utterances(["utt0.npy", "utt1.npy"], w)[r]
+    n_batches = len(DD.plan_batches(mine, [5] * len(mine), 4))
+    D.barrier()
+    q.put((r, int(buf.numel()), mine, n_batches))
+    torch.distributed.destroy_process_group()
+
+
+def test_more_ranks_than_utterances_world3():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert [r[2] for r in res] == [["utt0.npy"], ["utt1.npy"], []]
+    assert [r[3] for r in res] == [1, 1, 0]

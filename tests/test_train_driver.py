@@ -69,7 +69,7 @@ def test_optimizer_list_excludes_scale_in_and_checkpoint_keys(tmp_path):
     assert plist[0] is next(m.conv_aux.parameters())
     opt = torch.optim.Adam(plist, lr=1e-4)
     T.save_checkpoint(str(tmp_path), m, opt, np.random.get_state(), torch.get_rng_state(), 7)
-    ck = torch.load(str(tmp_path / "checkpoint-7.pkl"), weights_only=False)
+    ck = torch.load(str(tmp_path / "checkpoint-7.pkl"), weights_only=True)
     assert set(ck) == {"model", "optimizer", "numpy_random_state", "torch_random_state", "iterations"}
     assert list(ck["model"]) == list(m.state_dict()) and ck["iterations"] == 7
 
