@@ -143,13 +143,88 @@ def gen_laplace(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, with_for
         f1 = [frames[solo_of]]
         aux1 = aux[solo_of:solo_of + 1, :, : f1[0]].copy()
         rows = noise[: int(n_samples[solo_of] / cfg.seg), solo_of:solo_of + 1]
-        P = cpu_ref.as_params(sd)
-        solo = cpu_ref.laplace_generate(cfg, P, torch.from_numpy(aux1), [n_samples[solo_of]], rows)
+        # the REFERENCE decodes the solo utterance, fed its own rows of the recorded noise through a replaying uniform_
+        # (lpc>0: one (1,1,1) draw per sample; lpc==0: one (1,1,seg) draw per step - the order `rows` is stored in)
+        queue = [torch.from_numpy(np.ascontiguousarray(r)) for r in
+                 (rows.reshape(-1, 1, 1, 1) if cfg.lpc > 0 else rows.reshape(-1, 1, 1, cfg.seg))]
+        cursor = [0]
+
+        def replay_uniform(self, *a, **k):
+            self.copy_(queue[cursor[0]].reshape(self.shape))
+            cursor[0] += 1
+            return self
+
+        torch.Tensor.uniform_ = replay_uniform
+        try:
+            solo = m.batch_fast_generate(torch.zeros(1, cfg.seg), torch.from_numpy(aux1), [n_samples[solo_of]], 4410)
+        finally:
+            torch.Tensor.uniform_ = orig_uniform
+        assert cursor[0] == len(queue)
         out["solo_index"] = solo_of
-        out["solo_samples"] = solo[0]
+        out["solo_samples"] = solo[0].astype(np.float32)
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(f"[golden] {name}: steps={n_steps} B={B} {time.time() - t0:.1f}s "
           f"|s|max={max(np.abs(s).max() for s in samples):.3f}")
+
+
+def grad_sample_index(size: int, n: int = 2048) -> np.ndarray:
+    """the fixed element subset of a large gradient tensor that g7 fixtures store (tests re-derive it)."""
+    return np.unique(np.linspace(0, size - 1, min(n, size)).astype(np.int64))
+
+
+def _store_grads(out, m):
+    for k, p in m.named_parameters():
+        gnp = p.grad.numpy() if p.grad is not None else np.zeros(tuple(p.shape), np.float32)
+        out[f"gdig_{k}"] = digest(gnp)
+        if gnp.size <= 4096:
+            out[f"grad_{k}"] = gnp
+        else:
+            out[f"gsamp_{k}"] = gnp.ravel()[grad_sample_index(gnp.size)]
+            out[f"gnorm_{k}"] = np.float64(np.sqrt((gnp.astype(np.float64) ** 2).sum()))
+
+
+def gen_teacher_forced(name, cfg, frames, wseed, flavor, aux_seed):
+    """G7: the teacher-forced stack AT THE run.sh GEOMETRY through the reference itself - `CSWNV.forward` (+clip) and
+    `LaplaceLoss().backward()`, or `DSWNV.forward` and cross-entropy backward - on a ragged B=2 batch a little longer
+    than the receptive field.  Outputs are stored whole (Laplace) or as head / tail / every 16th position (logits);
+    gradients whole up to 4096 elements, otherwise digest + norm + a fixed 2048-element subset."""
+    t0 = time.time()
+    m, sd = build_ref(cfg, wseed, flavor)
+    aux = ragged_aux(cfg, frames, aux_seed)
+    B, T = len(frames), max(frames) * cfg.U
+    rng = np.random.Generator(np.random.PCG64([aux_seed, 77]))
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, flavor=np.array(flavor), frames=np.array(frames), aux=aux)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    if cfg.kind == "laplace":
+        audio = rng.uniform(-0.9, 0.9, size=(B, 1, T - cfg.seg)).astype(np.float32)
+        res = m(torch.from_numpy(aux), torch.from_numpy(audio), do=False, clip=False)
+        out["fwd_audio"] = audio
+        for i, r in enumerate(res):
+            out[f"fwd_{i}"] = r.detach().numpy()
+        resc = m(torch.from_numpy(aux), torch.from_numpy(audio), do=False, clip=True)
+        out["fwd_clip_n"] = len(resc)
+        mu, b, log_b = res[0], res[1], res[2]
+        tgt = torch.from_numpy(rng.uniform(-0.9, 0.9, size=tuple(mu.shape)).astype(np.float32))
+        loss = ref_c.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
+        if cfg.lpc > 0:
+            loss = loss + 0.1 * res[3].pow(2).mean()
+    else:
+        Q = cfg.n_quantize
+        idx_in = rng.integers(0, Q, size=(B, T - 1)).astype(np.int64)
+        logits = m(ref_d.OneHot(torch.from_numpy(idx_in), Q).transpose(1, 2), torch.from_numpy(aux))
+        ln = logits.detach().numpy()
+        out["fwd_audio_idx"] = idx_in
+        out["fwd_logits_dig"] = digest(ln)
+        out["fwd_logits_head"], out["fwd_logits_tail"], out["fwd_logits_s16"] = ln[:, :64], ln[:, -64:], ln[:, ::16]
+        tgt = torch.from_numpy(rng.integers(0, Q, size=(B, T - 1)).astype(np.int64))
+        loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, Q), tgt.reshape(-1))
+    loss.backward()
+    out["loss_target"] = tgt.numpy()
+    out["loss"] = np.float64(loss.item())
+    _store_grads(out, m)
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: B={B} T={T} rf={cfg.receptive_field} loss={loss.item():.5f} {time.time() - t0:.1f}s")
 
 
 def gen_softmax(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, head_stride=1,
@@ -504,6 +579,13 @@ def main():
         jobs.append(("g2_ref6_softmax_b1", gen_softmax,
                      dict(cfg=C.ref6_softmax(), frames=[14], wseed=33, flavor="xavier", aux_seed=6,
                           noise_seed=17, with_forward=False, head_stride=8)))
+        # ---- G7 REF6 teacher-forced forward + backward through the reference (B=2 ragged, T = 990 > rf = 690)
+        jobs.append(("g7_ref6_tf_laplace_s1l4", gen_teacher_forced,
+                     dict(cfg=C.ref6_laplace(1, 4), frames=[9, 8], wseed=41, flavor="trained", aux_seed=8)))
+        jobs.append(("g7_ref6_tf_laplace_s5l4", gen_teacher_forced,
+                     dict(cfg=C.ref6_laplace(5, 4), frames=[9, 8], wseed=42, flavor="xavier", aux_seed=8)))
+        jobs.append(("g7_ref6_tf_smx", gen_teacher_forced,
+                     dict(cfg=C.ref6_softmax(), frames=[9, 7], wseed=43, flavor="xavier", aux_seed=8)))
     for name, fn, kw in jobs:
         if args.only and args.only not in name:
             continue

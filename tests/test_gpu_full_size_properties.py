@@ -111,3 +111,44 @@ def test_softmax_full_size_sampling_and_stack(gpu_ok):
     lo = 2 * cfg.receptive_field
     d = (raw[0].transpose(0, 1)[lo:] - logits[0, lo + 1:n]).abs().max().item()
     assert d <= 2e-4, d
+
+
+def test_cfg3_full_size_lpc_recursion_and_stack(gpu_ok):
+    """cfg3 (BL6 Laplace, seg = 5, lpc = 4, Tf = 600 -> 13 200 steps of 5 samples) at its full size:
+      * LP recursion law per sub-step (cswnv_shift1.py:368-385): with a = heads[2seg:] used FLIPPED against the last
+        lpc generated samples (zeros before the start), s_j = clamp(a . buf + mu_j - sigmoid(.)_j * sign(e) log1p(-2|e|));
+      * the teacher-forced stack fed with the generated waveform reproduces the heads of step i at its position
+        (i-1)*seg past two receptive fields;
+      * a prefix of the decode is bit-identical to the shorter decode."""
+    cfg = C.bl6_laplace(seg=5, lpc=4)
+    seg, lpc = cfg.seg, cfg.lpc
+    net = HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True), "cuda:0")
+    n_steps = TF * cfg.U // seg
+    n = n_steps * seg
+    aux = torch.from_numpy(synth_aux(cfg, 1, TF, seed=3)).cuda()
+    noise = NZ.laplace_uniform(cfg, n_steps, 1, generator=torch.Generator().manual_seed(3)).cuda()
+    out, heads = net.decode(aux, n_steps, noise, want_heads=True)
+    assert out.shape == (1, n) and heads.shape == (1, n_steps, 2 * seg + lpc)
+    got = out[0].double().cpu().numpy()
+    h = heads[0].double().cpu().numpy()
+    e = noise[0].double().cpu().numpy().reshape(-1)                              # (step, j) order
+    mu = h[:, :seg].reshape(-1)
+    b = (1.0 / (1.0 + np.exp(-h[:, seg:2 * seg]))).reshape(-1)
+    a = np.repeat(h[:, 2 * seg:], seg, axis=0)                                   # (n, lpc), the step's coefficients
+    hist = np.concatenate([np.zeros(lpc), got])                                  # hist[p + k] = x[p - lpc + k]
+    win = np.lib.stride_tricks.sliding_window_view(hist, lpc)[:n]                # win[p, k] = x[p - lpc + k]
+    pred = (a[:, ::-1] * win).sum(1)
+    want = np.clip(pred + mu - b * np.sign(e) * np.log1p(-2.0 * np.abs(e)), -1.0, 1.0)
+    assert np.isfinite(got).all() and got.std() > 1e-3
+    assert np.abs(got - want).max() <= 5e-6, np.abs(got - want).max()
+    audio = out[:, None, : n - seg].contiguous()
+    raw = net.forward(aux, audio)
+    raw = raw[0] if isinstance(raw, tuple) else raw
+    assert raw.shape[2] == n - 2 * seg + 1
+    i0 = 2 * cfg.receptive_field // seg + 2
+    steps = torch.arange(i0, n_steps - 1, device=raw.device)
+    d = (raw[0].transpose(0, 1)[(steps - 1) * seg] - heads[0, steps]).abs().max().item()
+    assert d <= 2e-5, d
+    m = 2345
+    short, _ = net.decode(aux, m, noise[:, :m].contiguous())
+    assert torch.equal(short[0], out[0, : m * seg])

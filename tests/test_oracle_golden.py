@@ -208,3 +208,57 @@ def test_dropout_masks_and_oracle_reproduce_the_reference_training_forward(name)
         lg = raw.transpose(1, 2).numpy()
         assert np.abs(lg[:, :64] - d["fwd_logits_head"]).max() <= 2e-4
         assert np.abs(lg[:, -64:] - d["fwd_logits_tail"]).max() <= 2e-4
+
+
+# ---- G7: teacher-forced forward + backward AT THE run.sh GEOMETRY (H=192/256, K=7), produced by the reference
+G7 = [n for n in golden_names() if n.startswith("g7_")]
+
+
+def grad_sample_index(size, n=2048):
+    """same subset rule as oracle/make_golden.py::grad_sample_index"""
+    return np.unique(np.linspace(0, size - 1, min(n, size)).astype(np.int64))
+
+
+def check_grads_against_fixture(name, grads, d, atol=2e-5, rtol=2e-4):
+    """grads: {state_dict key: ndarray}.  Elementwise on what the fixture stores (whole tensor or the fixed subset),
+    digests on the rest."""
+    for k, g in grads.items():
+        g = np.asarray(g, dtype=np.float64)
+        dig = d[f"gdig_{k}"]
+        scale = max(1e-3, dig[1])
+        assert abs(g.sum() - dig[0]) <= 5e-4 * scale, (name, k, g.sum(), dig[0])
+        assert abs(np.abs(g).sum() - dig[1]) <= 5e-4 * scale, (name, k)
+        if f"grad_{k}" in d:
+            ref, got = d[f"grad_{k}"], g
+        else:
+            ref, got = d[f"gsamp_{k}"], g.ravel()[grad_sample_index(g.size)]
+        assert np.abs(got - ref).max() <= atol + rtol * np.abs(ref).max(), (name, k, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("name", G7)
+def test_oracle_teacher_forced_ref6_forward_and_gradients(name):
+    """the oracle's stack, differentiated by torch autograd on the CPU, against the reference's own outputs, loss
+    and loss.backward() at REF6 size (B=2 ragged, 990 positions, rf=690)."""
+    cfg, d = load_golden(name)
+    P = {k: v.clone().requires_grad_(True) for k, v in _params(cfg, d).items()}
+    aux = torch.from_numpy(d["aux"])
+    if cfg.kind == "laplace":
+        res = cpu_ref.laplace_forward(cfg, P, aux, torch.from_numpy(d["fwd_audio"]))
+        for i, r in enumerate(res):
+            assert np.abs(r.detach().numpy() - d[f"fwd_{i}"]).max() <= TOL, (name, i)
+        assert len(cpu_ref.laplace_forward(cfg, P, aux, torch.from_numpy(d["fwd_audio"]), clip=True)) == int(d["fwd_clip_n"])
+        loss = cpu_ref.laplace_nll(res[0], res[1], torch.from_numpy(d["loss_target"]), log_b=res[2])
+        if cfg.lpc > 0:
+            loss = loss + 0.1 * res[3].pow(2).mean()
+    else:
+        oh = cpu_ref.one_hot(torch.from_numpy(d["fwd_audio_idx"]), cfg.n_quantize).transpose(1, 2)
+        logits = cpu_ref.softmax_forward(cfg, P, oh, aux)
+        ln = logits.detach().numpy()
+        assert np.abs(ln[:, :64] - d["fwd_logits_head"]).max() <= 2e-5
+        assert np.abs(ln[:, -64:] - d["fwd_logits_tail"]).max() <= 2e-5
+        assert np.abs(ln[:, ::16] - d["fwd_logits_s16"]).max() <= 2e-5
+        loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), torch.from_numpy(d["loss_target"]).reshape(-1))
+    assert abs(loss.item() - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    loss.backward()
+    grads = {k: (P[k].grad.numpy() if P[k].grad is not None else np.zeros(tuple(P[k].shape), np.float32)) for k in P}
+    check_grads_against_fixture(name, grads, d)
