@@ -7,18 +7,25 @@ One "step" = one complete pass of the hot path over that batch: frame-rate front
 persistent decode launch (prologue + 66 000 generation steps), inputs (features, noise, packed
 weights) already resident in HBM, samples left in HBM.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--utts B] [--frames Tf]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--utts B] [--frames Tf] [--no-legs]
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 Prints ONE JSON line (rank 0).  `roofline` prices the decode kernel against the HBM roof with the
 ALGORITHMIC bytes of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle (a port of the
 reference's per-step op structure, oracle/cpu_ref.py) on a bounded sample of the same workload.
+
+At N=1 the line also carries `legs`: every other BASELINE.json config measured in the same run, each
+with its workload, value, the kernel that dominates it and its own roofline:
+  cfg1 (softmax 16 kHz), cfg3 (seg=5, lpc=4), cfg5's 64-utterance per-GPU share, the run.sh-geometry
+  (REF6) companions of cfg1/2/3/5, cfg4 (teacher-forced forward and full training step incl. Adam, BL6 and REF6,
+  fp32 and bf16), and `batch_fast_generate` as a caller sees it (noise draw + launch + device->host copy).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import platform
 import sys
 import time
 
@@ -29,10 +36,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from shallow_wavenet_amd import config as C, dist as D, noise as NZ           # noqa: E402
-from shallow_wavenet_amd.runtime import HipNet, pack_state_dict                # noqa: E402
+from shallow_wavenet_amd.runtime import HipNet, pack_state_dict, train_precision   # noqa: E402
 from shallow_wavenet_amd.synth import synth_aux, synth_state_dict              # noqa: E402
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak
+MFMA_FP32_TFLOPS = 157.0         # fp32 matrix peak (exact-fp32 MFMA parity kernels)
 
 # HBM bytes per decode launch from rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.csv), keyed by
 # (utterances per GPU, frames): 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes,
@@ -45,14 +54,23 @@ def algorithmic_bytes_per_position(cfg: C.NetConfig, batch: int) -> float:
     """4*W_step + 4*W_inx/U + B*(4*A0/U + state_rd + state_wr + 4)  (fp32)."""
     H, S, K, L, U = cfg.H, cfg.S, cfg.K, cfg.L, cfg.U
     hin = cfg.causal_in
-    w_causal = H * hin * K + H + (2 * H if cfg.wav_conv_flag else 0)
+    if cfg.kind == "softmax" and not cfg.wav_conv_flag:
+        w_causal = H * K + H                          # one-hot input: only K columns of `causal` are touched
+    else:
+        w_causal = H * hin * K + H + ((hin if cfg.kind == "softmax" else 1) * H + H if cfg.wav_conv_flag else 0)
     w_layers = L * (2 * H * H * K + 2 * H + S * H + S)
     w_head = cfg.out1_chn * S + cfg.out1_chn + cfg.n_out * cfg.out1_chn + cfg.n_out
     w_step = w_causal + w_layers + w_head
     w_inx = L * (2 * H * cfg.A + 2 * H)
-    state_rd = 4 * (L * K * H + K * hin)
+    hin_state = H if cfg.wav_conv_flag else (1 if cfg.kind == "laplace" else 1)
+    state_rd = 4 * (L * K * H + K * hin_state)
     state_wr = 4 * (L * H + H)
     return 4 * w_step + 4 * w_inx / U + batch * (4 * cfg.A0 / U + state_rd + state_wr + 4)
+
+
+def stack_macs_per_position(cfg: C.NetConfig) -> int:
+    """teacher-forced forward with in_x hoisted: L x (2H^2K + SH) + out_1 + out_2."""
+    return cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.out1_chn * cfg.S + cfg.n_out * cfg.out1_chn
 
 
 def host_threads() -> int:
@@ -64,55 +82,269 @@ def host_threads() -> int:
     return max(1, min(n, 16))
 
 
-def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 50):
-    """time the oracle's free-running decode (reference per-step op structure) on the host cores."""
+def cpu_model() -> str:
+    try:
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.lower().startswith("model name"):
+                    return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return platform.processor() or "unknown"
+
+
+def _hip_timed(fn, reps: int, warm: int = 1):
+    """mean ms per call, HIP events on torch's current stream (the stream every launch helper uses)."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _hbm(bytes_per_launch: float, ms: float, **extra):
+    ach = bytes_per_launch / (ms * 1e-3) / 1e9
+    return dict(bound="hbm", achieved=round(ach, 2), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 5),
+                traffic=None, **extra)
+
+
+def _mfma(flops_per_launch: float, ms: float, peak: float, **extra):
+    ach = flops_per_launch / (ms * 1e-3) / 1e12
+    return dict(bound="mfma", achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 5),
+                traffic=None, **extra)
+
+
+# ------------------------------------------------------------------------------------------- cpu baseline
+def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 20, runs: int = 3):
+    """the oracle's free-running decode (reference per-step op structure) on the host cores: >= 2 000 steady-state
+    steps past the prologue, median of `runs`, for 1 thread and for the cores this process owns; the better is
+    reported."""
     from oracle import cpu_ref                      # checker only: never on the measured GPU path
     P = cpu_ref.as_params(sd)
     aux = torch.from_numpy(synth_aux(cfg, 1, frames))
     n = frames * cfg.U
     g = torch.Generator().manual_seed(1)
     noise = cpu_ref.laplace_noise(cfg, n // cfg.seg, 1, generator=g)
-    best = None
     ncores = host_threads()
-    for threads in sorted({1, min(ncores, 8)}):
+    results = {}
+    for threads in sorted({1, ncores}):
         torch.set_num_threads(threads)
-        t0 = time.time()
-        cpu_ref.laplace_generate(cfg, P, aux, [n], noise)
-        dt = time.time() - t0
-        rate = n / dt
-        if best is None or rate > best[0]:
-            best = (rate, threads)
+        rates = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            cpu_ref.laplace_generate(cfg, P, aux, [n], noise)
+            rates.append(n / (time.perf_counter() - t0))
+        results[threads] = float(np.median(rates))
     torch.set_num_threads(ncores)
-    return {"value": round(best[0], 1), "unit": "samples/s", "cores": best[1], "kind": "port",
-            "sample": f"cfg2 B=1 Tf={frames} ({n} generated samples) free-running oracle decode"}
+    best = max(results, key=results.get)
+    return {"value": round(results[best], 1), "unit": "samples/s", "cores": best, "kind": "port",
+            "cores_available": ncores, "cpu_model": cpu_model(),
+            "by_threads": {str(k): round(v, 1) for k, v in results.items()},
+            "sample": f"cfg2 B=1 Tf={frames}: {n} generated samples after the {cfg.receptive_field}-position prologue, "
+                      f"free-running oracle decode, median of {runs} runs",
+            "note": "the port drops the reference's two growing torch.cat buffers (O(T^2), cswnv_shift1.py:359-364,"
+                    "400-412), so it runs ~2.8x faster than the reference itself did on 8 container cores "
+                    "(418 samples/s, SURVEY.md section 6): the baseline is flattered, not the GPU"}
 
 
-def stack_leg(cfg: C.NetConfig, net: HipNet, dev, batch: int = 64, frames: int = 150, reps: int = 10):
-    """teacher-forced bf16 stack (cfg4 family, the home of the fused residual-block kernel) priced against the
-    HBM roof: algorithmic bytes per position = h0 write 2H + L x (read h, write h') 4H + head reads 2LH +
-    raw output 4*n_out + audio 4, conditioning 4*2H*L/U; HIP events on the launch stream."""
-    T = frames * cfg.U
-    aux = torch.from_numpy(synth_aux(cfg, batch, frames, seed=7)).to(dev)
-    audio = (torch.rand(batch, T - cfg.seg, device=dev) * 2 - 1) * 0.5
+# ------------------------------------------------------------------------------------------- legs
+def _net(cfg, dev, seed=1):
+    sd = synth_state_dict(cfg, seed=seed, flavor="trained", identity_scale_in=True)
+    return HipNet.from_state_dict(cfg, sd, dev), sd
+
+
+def _module(cfg, sd, dev):
+    from shallow_wavenet_amd.nets import cswnv_shift1 as mc, dswnv as md
+    m = (md.DSWNV if cfg.kind == "softmax" else mc.CSWNV)(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    return m.to(dev).eval()
+
+
+def decode_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, fs: int, reps: int, kernel: str, variant: int = 0,
+               caller: bool = False):
+    """one decode workload: kernel time by HIP events (inputs resident), samples/s, real-time factor per utterance,
+    HBM roofline on SURVEY 8(d)'s algorithmic bytes; optionally `batch_fast_generate` as the caller sees it."""
+    soft = cfg.kind == "softmax"
+    seg = 1 if soft else cfg.seg
+    n_steps = Tf * cfg.U // seg
+    net, sd = _net(cfg, dev)
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf, seed=11)).to(dev)
+    g = torch.Generator().manual_seed(11)
+    t0 = time.perf_counter()
+    noise = (NZ.softmax_exponential(cfg, n_steps, B, generator=g) if soft
+             else NZ.laplace_uniform(cfg, n_steps, B, generator=g))
+    host_noise_s = time.perf_counter() - t0
+    noise = noise.to(dev)
     cond = net.frontend(aux)
-    for _ in range(2):
-        net.forward_bf16(aux, audio, cond=cond)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        net.forward_bf16(aux, audio, cond=cond)
-    e1.record()
-    torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    ms = _hip_timed(lambda: net.decode(aux, n_steps, noise, cond=cond, variant=variant), reps, warm=1)
+    samples = B * n_steps * seg
+    positions = n_steps + (cfg.receptive_field - seg + 1) // seg
+    bpp = algorithmic_bytes_per_position(cfg, B)
+    leg = {"workload": name, "utterances": B, "frames": Tf, "steps": n_steps, "samples": samples,
+           "kernel_ms": round(ms, 3), "us_per_step": round(ms * 1e3 / positions, 3),
+           "value": round(samples / (ms * 1e-3), 1), "unit": "samples/s",
+           "real_time_factor_per_utterance": round(n_steps * seg / (ms * 1e-3) / fs, 2),
+           "host_noise_draw_s": round(host_noise_s, 4),
+           "roofline": _hbm(bpp * positions, ms, kernel=kernel, algorithmic_bytes_per_position=round(bpp, 1),
+                            positions_per_launch=positions)}
+    if caller:
+        m = _module(cfg, sd, dev)
+        m.set_packed_engine(net)
+        n_list = [n_steps * seg] * B
+        seed_in = (torch.full((B, 1), cfg.n_quantize // 2, dtype=torch.int64, device=dev) if soft
+                   else torch.zeros(B, seg, device=dev))
+        walls = []
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m.batch_fast_generate(seed_in, aux, n_list, 4410)
+            walls.append(time.perf_counter() - t0)
+        w = min(walls)
+        leg["batch_fast_generate"] = {"wall_s": round(w, 4), "value": round(samples / w, 1), "unit": "samples/s",
+                                      "real_time_factor_per_utterance": round(n_steps * seg / w / fs, 2),
+                                      "includes": "front end + noise draw + decode launch + device->host copy "
+                                                  "(cswnv_shift1.py:405-426 / dswnv.py:376-395)",
+                                      "wall_over_kernel": round(w / (ms * 1e-3), 3)}
+    return leg
+
+
+def forward_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps: int, kernel: str):
+    """teacher-forced forward (cfg4 family).  BL6 is HBM-bound (algorithmic bytes per position: h0 write + L x (read h,
+    write h') + head reads + raw output + audio + conditioning), REF6 MFMA-bound (2 x MAC)."""
+    net, _ = _net(cfg, dev)
+    soft = cfg.kind == "softmax"
+    T = Tf * cfg.U
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf, seed=7)).to(dev)
+    if soft:
+        audio = torch.randint(0, cfg.n_quantize, (B, T - 1), device=dev)
+    else:
+        audio = (torch.rand(B, 1, T - cfg.seg, device=dev) * 2 - 1) * 0.5
+    cond = net.frontend(aux)
+    fn = (lambda: net.forward_bf16(aux, audio, cond=cond)) if mode == "bf16" else (lambda: net.forward(aux, audio, cond=cond))
+    ms = _hip_timed(fn, reps, warm=2)
+    pos = B * (T - 1 if soft else T - 2 * cfg.seg + 1)
     H, L = cfg.H, cfg.L
-    bpp = 2 * H + L * 4 * H + 2 * L * H + 4 * cfg.n_out + 4 + 4 * 2 * H * L / cfg.U
-    pos = batch * T
-    ach = bpp * pos / (ms * 1e-3) / 1e9
-    return {"workload": f"teacher-forced bf16 forward, BL6, {batch} x {T} positions (input + {L} fused residual blocks + head)",
-            "ms": round(ms, 4), "positions_per_s": round(pos / (ms * 1e-3), 1), "bound": "hbm",
-            "algorithmic_bytes_per_position": round(bpp, 1), "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-            "note": "per-kernel split: profiles/r01_forward_b64_kernel_stats.csv (bf16_layer_units_kernel 46 % of the roof)"}
+    leg = {"workload": name, "batch": B, "positions": pos, "ms": round(ms, 4), "precision": mode,
+           "value": round(pos / (ms * 1e-3), 1), "unit": "positions/s"}
+    flops = 2.0 * stack_macs_per_position(cfg) * pos
+    leg["tflops"] = round(flops / (ms * 1e-3) / 1e12, 2)
+    if cfg.H <= 64:
+        eb = 2 if mode == "bf16" else 4
+        bpp = eb * H + L * 2 * eb * H + eb * L * H + 4 * cfg.n_out + 4 + 4 * 2 * H * L / cfg.U
+        leg["roofline"] = _hbm(bpp * pos, ms, kernel=kernel, algorithmic_bytes_per_position=round(bpp, 1))
+    else:
+        leg["roofline"] = _mfma(flops, ms, MFMA_BF16_TFLOPS if mode == "bf16" else MFMA_FP32_TFLOPS, kernel=kernel,
+                                algorithmic_flops_per_position=2 * stack_macs_per_position(cfg))
+    return leg
+
+
+def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps: int, kernel: str):
+    """one full training step of the drop-in module as train_cswnv...py:700-874 runs it: forward, LaplaceLoss,
+    backward (HIP kernels behind autograd), Adam step - the parameter re-pack that follows an optimizer step is
+    inside the timed loop."""
+    from shallow_wavenet_amd.nets import cswnv_shift1 as mc
+    sd = synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True)
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.to(dev).train()
+    for p in m.scale_in.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    T = Tf * cfg.U
+    Tp = T - 2 * cfg.seg + 1
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf, seed=7)).to(dev)
+    audio = (torch.rand(B, 1, T - cfg.seg, generator=torch.Generator().manual_seed(2)) * 1.8 - 0.9).to(dev)
+    tgt = (torch.rand(B, Tp, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9).to(dev)
+    crit = mc.LaplaceLoss()
+
+    def step(with_opt=True):
+        res = m(aux, audio)
+        loss = crit(res[0].reshape(B, Tp), res[1].reshape(B, Tp), tgt, log_b=res[2].reshape(B, Tp), log=False)
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        if with_opt:
+            opt.step()
+        return loss
+
+    with train_precision(mode):
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        ms_nopt = _hip_timed(lambda: step(False), reps, warm=1)
+    pos = B * Tp
+    flops = 3 * 2.0 * stack_macs_per_position(cfg) * pos
+    leg = {"workload": name, "batch": B, "positions": pos, "precision": mode, "ms": round(ms, 3),
+           "ms_forward_backward_only": round(ms_nopt, 3), "value": round(pos / (ms * 1e-3), 1), "unit": "positions/s",
+           "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
+           "includes": "forward + LaplaceLoss + backward + Adam step + parameter re-pack, wall clock"}
+    peak = MFMA_BF16_TFLOPS if mode == "bf16" else MFMA_FP32_TFLOPS
+    leg["roofline"] = _mfma(flops, ms, peak, kernel=kernel, algorithmic_flops="3 x forward (2 x MAC)")
+    return leg
+
+
+def run_legs(dev, quick: bool = False):
+    legs = {}
+
+    def add(key, fn, *a, **k):
+        t0 = time.perf_counter()
+        try:
+            legs[key] = fn(*a, **k)
+        except Exception as e:                                  # noqa: BLE001  a leg must not cost the line
+            legs[key] = {"error": f"{type(e).__name__}: {e}"}
+        legs[key]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+
+    bl6 = C.bl6_laplace(1, 0)
+    add("cfg2_caller", decode_leg, "cfg2: CSWNV BL6 seg=1 lpc=0, 22.05 kHz, 1 utterance x Tf=600, batch_fast_generate as called",
+        bl6, dev, 1, 600, 22050, 1, "decode_bl6_kernel", caller=True)
+    add("cfg1", decode_leg, "cfg1: DSWNV BL6 softmax mu-law 256 (H=64, S=256, K=2), 16 kHz, 1 utterance x Tf=600 (48 000 steps)",
+        C.bl6_softmax(), dev, 1, 600, 16000, 2, "decode_bl6_kernel<softmax>", caller=True)
+    add("cfg3", decode_leg, "cfg3: CSWNV BL6 seg=5 lpc=4 (multi-sample output + LP), 22.05 kHz, 1 utterance x Tf=600 (13 200 steps)",
+        C.bl6_laplace(5, 4), dev, 1, 600, 22050, 3, "decode_bl6_kernel<seg5,lpc4>", caller=True)
+    add("cfg5_share", decode_leg, "cfg5 per-GPU share: 64 utterances x Tf=600, CSWNV BL6 seg=1 lpc=0 (one workgroup per utterance)",
+        bl6, dev, 64, 600, 22050, 2, "decode_bl6_kernel")
+    # run.sh geometry (REF6: 3x2 layers, K=7, H=192/256): companions of cfg1/2/3/5, 440-step decodes (+690-position prologue)
+    r_tf = 4
+    stepped = "stepped decode: step_layer_kernel x L + rowvec_kernel x 2 + step_tail_kernel per step"
+    add("ref6_cfg2", decode_leg, "REF6 companion of cfg2: CSWNV run.sh geometry (H=192, S=256, K=7, 3x2) seg=1 lpc=4, 1 utterance x Tf=4",
+        C.ref6_laplace(1, 4), dev, 1, r_tf, 22050, 2, stepped)
+    add("ref6_cfg3", decode_leg, "REF6 companion of cfg3: seg=5 lpc=4, 1 utterance x Tf=4",
+        C.ref6_laplace(5, 4), dev, 1, r_tf, 22050, 2, stepped)
+    add("ref6_cfg1", decode_leg, "REF6 companion of cfg1: DSWNV run.sh geometry (H=256, K=7, 3x2, Q=256), 22.05 kHz, 1 utterance x Tf=4",
+        C.ref6_softmax(), dev, 1, r_tf, 22050, 2, stepped)
+    add("ref6_cfg5_share", decode_leg, "REF6 companion of cfg5's share: 64 utterances x Tf=4, seg=1 lpc=4",
+        C.ref6_laplace(1, 4), dev, 64, r_tf, 22050, 1, stepped)
+    if quick:
+        return legs
+    # cfg4: teacher-forced stack, 8 x 16 500 (BASELINE's size) and 64 x 16 500
+    units = "bf16_layer_units_kernel x 6 + bf16_input_kernel + bf16_head_kernel"
+    add("cfg4_bl6_fwd_bf16", forward_leg, "cfg4 forward: BL6, 8 x 16 500 positions, bf16 MFMA stack", bl6, dev, 8, 150, "bf16", 20, units)
+    add("cfg4_bl6_fwd_bf16_b64", forward_leg, "cfg4 forward at 8x the batch: BL6, 64 x 16 500 positions, bf16 MFMA stack", bl6, dev, 64, 150, "bf16", 10, units)
+    add("cfg4_bl6_fwd_fp32", forward_leg, "cfg4 forward: BL6, 8 x 16 500 positions, fp32 parity kernels", bl6, dev, 8, 150, "fp32", 10,
+        "tf_layer_kernel x 6 + gemm_wx_kernel x 3")
+    ref6 = C.ref6_laplace(1, 4)
+    add("cfg4_ref6_fwd_bf16", forward_leg, "cfg4 forward: REF6 (run.sh geometry), 8 x 16 500 positions, bf16 GEMM stack", ref6, dev, 8, 150, "bf16", 5,
+        "bf16g_gemm_kernel<gate> x 6 + <relu> x 2 + <out>")
+    add("cfg4_ref6_fwd_fp32", forward_leg, "cfg4 forward: REF6, 8 x 16 500 positions, fp32 parity kernels (exact-fp32 MFMA)", ref6, dev, 8, 150, "fp32", 2,
+        "tf_layer_kernel x 6 + gemm_wx_kernel x 3")
+    add("cfg4_bl6_step_bf16", train_leg, "cfg4 training step: BL6, 8 x 16 500, mixed precision", bl6, dev, 8, 150, "bf16", 5,
+        "bf16 forward + gate_bwd / time_gemm_bf16t / reduce_gemm_bf16s per layer")
+    add("cfg4_bl6_step_fp32", train_leg, "cfg4 training step: BL6, 8 x 16 500, fp32 parity mode", bl6, dev, 8, 150, "fp32", 3,
+        "tf_layer + time_gemm / reduce_gemm (exact-fp32 MFMA)")
+    add("cfg4_ref6_step_bf16", train_leg, "cfg4 training step: REF6, 8 x 16 500, mixed precision", ref6, dev, 8, 150, "bf16", 3,
+        "bf16g_gemm + time_gemm_bf16t / reduce_gemm_bf16s")
+    add("cfg4_ref6_step_fp32", train_leg, "cfg4 training step: REF6, 8 x 16 500, fp32 parity mode", ref6, dev, 8, 150, "fp32", 2,
+        "tf_layer + time_gemm / reduce_gemm (exact-fp32 MFMA)")
+    return legs
 
 
 def main():
@@ -123,6 +355,8 @@ def main():
     ap.add_argument("--utts", type=int, default=1, help="utterances per GPU (cfg2: 1; cfg5: 64)")
     ap.add_argument("--frames", type=int, default=600, help="conditioning frames per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
+    ap.add_argument("--quick-legs", action="store_true", help="decode legs only")
     args = ap.parse_args()
 
     rank, world, local = D.init_from_env()
@@ -192,17 +426,21 @@ def main():
                      "algorithmic_bytes_per_position": round(bytes_pos, 1), "positions_per_launch": positions,
                      "note": "latency-bound sequential chain; working set is L2/LDS/VGPR resident (SURVEY 7.3)"},
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        # auxiliary legs: a failure there must not cost the headline line
-        try:
-            line["stack"] = stack_leg(cfg, net, dev)
-        except Exception as e:                                  # noqa: BLE001
-            line["stack"] = {"error": f"{type(e).__name__}: {e}"}
-        try:
-            line["cpu_baseline"] = cpu_baseline(cfg, sd)
-        except Exception as e:                                  # noqa: BLE001
-            line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
-                                    "sample": f"failed: {type(e).__name__}: {e}"}
+    if rank == 0 and world == 1:
+        # auxiliary measurements: a failure there must not cost the headline line
+        if not args.no_legs:
+            t_legs = time.perf_counter()
+            line["legs"] = run_legs(dev, quick=args.quick_legs)
+            line["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
+            # kept for continuity with round 1's line: the fused residual-block stack at 64 x 16 500
+            if "cfg4_bl6_fwd_bf16_b64" in line["legs"]:
+                line["stack"] = line["legs"]["cfg4_bl6_fwd_bf16_b64"]
+        if not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(cfg, sd)
+            except Exception as e:                                  # noqa: BLE001
+                line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if world > 1:
