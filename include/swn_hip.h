@@ -14,7 +14,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Launches are
  *     asynchronous; nothing in here synchronises, allocates or frees device memory.
  *   - every function returns 0 on success or a negative SWN_E_* code;
- *     swn_strerror() maps it to text.  No global mutable state.
+ *     swn_strerror() maps it to text.  No global mutable state except the one process-wide switch
+ *     swn_train_set_precision() (documented there); nothing reads the environment.
  */
 #ifndef SWN_HIP_H
 #define SWN_HIP_H
@@ -55,7 +56,7 @@ typedef struct swn_net_desc {
     int32_t n_quantize;        /* softmax only                                */
     int32_t wav_conv_flag;
     int32_t audio_in_flag;     /* softmax only                                */
-    int32_t aux_conv2d_flag;   /* laplace only (not built: SWN_E_UNSUPPORTED) */
+    int32_t aux_conv2d_flag;   /* laplace only; the (seg,1) Conv2d is folded into in_x at pack time */
 } swn_net_desc;
 
 /* ---- introspection --------------------------------------------------------------- */
@@ -84,6 +85,12 @@ size_t swn_packed_floats(const swn_net_desc* d);
 int    swn_layout_offsets(const swn_net_desc* d, size_t* out, int n);
 int    swn_pack_params(const swn_net_desc* d, const float* const* tensors_host, int n_tensors,
                        float* packed_host, size_t packed_floats);
+/* The same re-layout on the device, for parameters that already live in HBM (a training step ends with
+ * optimizer.step(), train_cswnv_laplace-stftcmplx_shift1.py:872-874, after which every packed section is stale):
+ *   tensors_dev  HOST array of n_tensors DEVICE pointers (state_dict order, fp32, contiguous, reference shapes)
+ *   packed_dev   swn_packed_floats() floats, overwritten (padding zeroed); bit-identical to swn_pack_params      */
+int    swn_pack_params_device(const swn_net_desc* d, const float* const* tensors_dev, int n_tensors,
+                              float* packed_dev, size_t packed_floats, void* stream);
 
 /* ---- frame-rate front end  (cswnv_shift1.py:193,297 / dswnv.py:252,302) ---------------
  * scale_in -> conv_aux (two-sided dilated k=3 stack) -> hoisted in_x:

@@ -52,6 +52,7 @@ SIGNATURES = {
     "swn_packed_floats": (c_size_t, [POINTER(NetDesc)]),
     "swn_layout_offsets": (c_int, [POINTER(NetDesc), POINTER(c_size_t), c_int]),
     "swn_pack_params": (c_int, [POINTER(NetDesc), POINTER(c_void_p), c_int, c_void_p, c_size_t]),
+    "swn_pack_params_device": (c_int, [POINTER(NetDesc), POINTER(c_void_p), c_int, c_void_p, c_size_t, c_void_p]),
     "swn_frontend_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_cond_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_frontend": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

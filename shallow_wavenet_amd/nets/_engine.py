@@ -15,7 +15,7 @@ import torch
 from torch import nn
 
 from ..config import NetConfig
-from ..runtime import HipNet
+from ..runtime import HipNet, pack_parameters_device
 
 
 def initialize(m):
@@ -93,7 +93,13 @@ class EngineMixin:
         key = self._engine_key()
         cache = self.__dict__.get("_engine_cache")
         if cache is None or cache[0] != key:
-            net = HipNet.from_state_dict(self._cfg, {k: v for k, v in self.state_dict().items()}, dev)
+            tensors = list(self.state_dict().values())
+            if cache is not None and cache[1].device == dev:
+                # parameters changed (optimizer step, load_state_dict): re-lay them out on the device, in place
+                net = cache[1]
+                net.repack(tensors)
+            else:
+                net = HipNet(self._cfg, pack_parameters_device(self._cfg, tensors), dev)
             self.__dict__["_engine_cache"] = (key, net)
             return net
         return cache[1]

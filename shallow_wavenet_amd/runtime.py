@@ -51,6 +51,38 @@ def pack_state_dict(cfg: NetConfig, state_dict: Dict[str, "np.ndarray | torch.Te
     return packed
 
 
+def pack_parameters_device(cfg: NetConfig, tensors: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None
+                           ) -> torch.Tensor:
+    """reference-layout parameter tensors ALREADY ON THE DEVICE (state_dict order) -> packed buffer on that device
+    (swn_pack_params_device): one launch, no host round trip; `out` is reused when given."""
+    L = _lib.lib()
+    desc = _lib.desc_from_cfg(cfg)
+    shapes = cfg.param_shapes()
+    if len(tensors) != len(shapes):
+        raise RuntimeError(f"{len(tensors)} tensors given, the configuration has {len(shapes)}")
+    dev = tensors[0].device
+    keep = []
+    for t, (name, shp) in zip(tensors, shapes):
+        if tuple(t.shape) != tuple(shp):
+            raise RuntimeError(f"{name}: shape {tuple(t.shape)} != reference shape {tuple(shp)}")
+        if t.device != dev or dev.type != "cuda":
+            raise RuntimeError(f"{name}: device-side packing needs every parameter on one HIP device")
+        t = t.detach()
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(torch.float32).contiguous()
+        keep.append(t)
+    total = L.swn_packed_floats(ctypes.byref(desc))
+    if out is None:
+        out = torch.empty(total, dtype=torch.float32, device=dev)
+    elif out.numel() != total or out.device != dev or out.dtype != torch.float32:
+        raise RuntimeError("packed output buffer has the wrong size / device")
+    ptrs = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
+    with torch.cuda.device(dev):
+        _lib.check(L.swn_pack_params_device(ctypes.byref(desc), ptrs, len(keep), _ptr(out), total, _stream_ptr(dev)),
+                   "pack_params_device")
+    return out
+
+
 LAYOUT_FIELDS = ("scale_w", "scale_b", "aux_w0", "aux_w1", "aux_w2", "aux_w3", "aux_b0", "aux_b1", "aux_b2", "aux_b3",
                  "wx", "wxa", "wup", "bup", "bx", "cb", "cv", "cc", "ct", "wd", "bd", "wsk", "bsk", "w1", "b1", "w2",
                  "b2", "total", "bxr")
@@ -98,6 +130,13 @@ class HipNet:
         self.device = torch.device(device)
         self.lib = _lib.lib()
         self.packed = packed.to(self.device, non_blocking=False).contiguous()
+        self.packed_version = 0          # bumped by repack(): derived copies (bf16 weights) follow it
+
+    def repack(self, tensors: Sequence[torch.Tensor]) -> None:
+        """refresh the packed buffer IN PLACE from the live parameter tensors on the device (after an optimizer
+        step); launches are stream-ordered behind whatever still reads the old values."""
+        pack_parameters_device(self.cfg, tensors, out=self.packed)
+        self.packed_version += 1
 
     @classmethod
     def from_state_dict(cls, cfg: NetConfig, state_dict, device) -> "HipNet":
@@ -189,10 +228,12 @@ class HipNet:
         if cond is None:
             cond = self.frontend(aux)
         B, Tf = cond.shape[0], cond.shape[1]
-        if getattr(self, "_wbf16", None) is None:
-            self._wbf16 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        if getattr(self, "_wbf16", None) is None or getattr(self, "_wbf16_version", -1) != self.packed_version:
+            if getattr(self, "_wbf16", None) is None:
+                self._wbf16 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
             with torch.cuda.device(self.device):
                 _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _stream_ptr(self.device)), "pack_bf16")
+            self._wbf16_version = self.packed_version
         soft = cfg.kind == "softmax"
         Tp = Tf * cfg.U - 1 if soft else Tf * cfg.U - 2 * cfg.seg + 1
         audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
@@ -251,7 +292,7 @@ class HipNet:
     def _bf16_train_forward(self, cond, audio, B, Tf, work):
         """mixed-precision mode: bf16 forward, then its bf16 activations expanded into the fp32 buffers swn_backward
         reads.  Returns None (caller runs the fp32 forward) where the library has no bf16 stack for the geometry.
-        The bf16 copy of the weights is refreshed on every call: the parameters move between training steps."""
+        The bf16 copy of the weights follows `packed_version` (bumped whenever the parameters were re-packed)."""
         L = self.lib
         d = ctypes.byref(self.desc)
         if L.swn_bf16_train_forward_supported(d) != 1:
@@ -265,7 +306,9 @@ class HipNet:
         out = torch.empty((B, self.cfg.n_out, Tp), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
             st = _stream_ptr(self.device)
-            _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), st), "pack_bf16")
+            if getattr(self, "_wbf16_version", -1) != self.packed_version:
+                _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), st), "pack_bf16")
+                self._wbf16_version = self.packed_version
             _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
                                           _ptr(wb), _ptr(out), st), "forward_bf16")
             _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), st), "bf16_work_to_f32")

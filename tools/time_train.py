@@ -12,6 +12,7 @@ from shallow_wavenet_amd.runtime import train_precision
 MODE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 train_precision(MODE)
 ONLY = sys.argv[4].upper() if len(sys.argv) > 4 else None      # optional 4th argument: bl6 | ref6
+WITH_OPT = len(sys.argv) > 5 and sys.argv[5] == "opt"           # optional 5th argument "opt": Adam step inside the loop
 for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     if ONLY and nm != ONLY:
         continue
@@ -24,6 +25,10 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     Tp = T - 2 * cfg.seg + 1
     tgt = (torch.rand(B, Tp, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9).cuda()
 
+    for p in m.scale_in.parameters():
+        p.requires_grad = False
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+
     def step():
         res = m(aux, audio)
         mu, b, log_b = res[0].reshape(B, Tp), res[1].reshape(B, Tp), res[2].reshape(B, Tp)
@@ -31,6 +36,8 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
         for p in m.parameters():
             p.grad = None
         loss.backward()
+        if WITH_OPT:
+            opt.step()
         return loss
 
     for _ in range(2): step()
@@ -42,4 +49,4 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     macs_fwd = (cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.S * cfg.S + cfg.n_out * cfg.S) * B * Tp
-    print(f"{nm} B={B} Tf={Tf} [{MODE}]: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
+    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
