@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SWN_ABI_VERSION 1
+#define SWN_ABI_VERSION 2
 
 #define SWN_KIND_LAPLACE 0   /* CSWNV, cswnv_shift1.py:130 */
 #define SWN_KIND_SOFTMAX 1   /* DSWNV, dswnv.py:190       */
@@ -110,10 +110,7 @@ int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float*
  * One persistent workgroup per utterance runs prologue (rf+1 seed positions) and all
  * n_steps steps; all utterances run n_steps = max(n_samples)/seg steps like the reference.
  *   cond_dev    (B, Tf, L*seg*2H)  from swn_frontend
- *   noise_dev   laplace: (B, n_steps, seg) uniform(-0.4999,0.5) draws; softmax: (B, n_steps, Q)
- *               Exp(1) draws  (host generates them in the reference's draw order)
- *   forced_dev  optional teacher forcing (may be NULL): laplace (B, n_steps*seg) fp32 samples,
- *               softmax (B, n_steps) int32 indices fed back instead of the generated ones
+ *   io          inputs of the sampling loop, see swn_decode_io below
  *   state_dev   swn_decode_state_floats() scratch (history rings; zeroed by the call)
  *   out_dev     laplace: (B, n_steps*seg) fp32 ; softmax: (B, n_steps) int32
  *   heads_dev   optional (B, n_steps, n_out) raw out_2 outputs at each step (may be NULL)
@@ -121,10 +118,32 @@ int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float*
  *               3 = stepped multi-launch decode for large geometries (REF6),
  *               4 = cohort decode of large geometries: up to 64 utterances in lock step, lanes = utterances
  *                   (explicit only; auto keeps the stepped decode)                                            */
+typedef struct swn_decode_io {
+    /* sampling noise.  noise_dev != NULL: the host-drawn stream (parity mode; the host draws it with the torch CPU
+     * generator in the reference's order): laplace (B, n_steps, seg) uniform(-0.4999, 0.5) draws
+     * (cswnv_shift1.py:373,380,387), softmax (B, n_steps, Q) Exp(1) draws (the multinomial of dswnv.py:364-365).
+     * noise_dev == NULL: the kernels draw the same quantities themselves with a counter-based generator
+     * (Philox4x32-10 keyed by rng_seed, counter = (rng_utt0 + b, step, element): csrc/swn_noise.hpp), like the
+     * reference drawing on the model's device; nothing is drawn, stored or uploaded by the host. */
+    const float* noise_dev;
+    /* optional teacher forcing (may be NULL): laplace (B, n_steps*seg) fp32 samples, softmax (B, n_steps) int32
+     * indices fed back instead of the generated ones */
+    const void*  forced_dev;
+    /* optional seed waveform `audio` of batch_fast_generate (may be NULL = the decode drivers' seed: zeros /
+     * mu-law class Q/2, decode_cswnv_laplace-shift1.py:93, decode_dswnv_softmax.py:94-99):
+     * laplace (B, seg) fp32 samples, softmax (B) int32 classes (cswnv_shift1.py:300-334, dswnv.py:305-336) */
+    const void*  seed_dev;
+    /* optional (may be NULL): every noise value used is also written here, layout of noise_dev - lets a test replay
+     * a device-drawn run in the CPU oracle ("given the same noise") */
+    float*       noise_out_dev;
+    uint64_t     rng_seed;      /* used when noise_dev == NULL */
+    uint32_t     rng_utt0;      /* global index of utterance 0: draws do not depend on batching or sharding */
+    uint32_t     reserved;      /* 0 */
+} swn_decode_io;
 size_t swn_decode_state_floats(const swn_net_desc* d, int batch);
 int    swn_decode(const swn_net_desc* d, const float* packed_dev, const float* cond_dev,
-                  int batch, int n_frames, int n_steps, const float* noise_dev,
-                  const void* forced_dev, float* state_dev, void* out_dev, float* heads_dev,
+                  int batch, int n_frames, int n_steps, const swn_decode_io* io,
+                  float* state_dev, void* out_dev, float* heads_dev,
                   int variant, void* stream);
 
 /* ---- teacher-forced stack  (CSWNV.forward cswnv_shift1.py:191-267,

@@ -200,8 +200,10 @@ def laplace_transform(eps: torch.Tensor) -> torch.Tensor:
 
 
 def laplace_generate(cfg, P, aux: torch.Tensor, n_samples_list: Sequence[int], noise,
-                     return_heads: bool = False):
-    """CSWNV.batch_fast_generate with the seed waveform zeros(B, seg).
+                     return_heads: bool = False, seed=None):
+    """CSWNV.batch_fast_generate; `seed` = its `audio` argument (B, seg), zeros when None (the decode driver's
+    seed, decode_cswnv_laplace-shift1.py:93): left-padded with rf zeros, it is the newest part of the first causal
+    window and of the LP buffer (cswnv_shift1.py:300-319).
 
     Keeps the reference's per-step op structure (window convolutions per layer, history
     buffers concatenated and slid) so that timing it is a fair CPU baseline; the growing
@@ -219,8 +221,10 @@ def laplace_generate(cfg, P, aux: torch.Tensor, n_samples_list: Sequence[int], n
         x = upsample(cfg, P, frontend(cfg, P, aux))
         x = _stack_seg(cfg, P, F.pad(x, (rf, 0), "replicate"))
         audio = torch.zeros(B, 1, rf + seg)
+        if seed is not None:
+            audio[:, 0, rf:] = torch.as_tensor(seed, dtype=torch.float32).reshape(B, seg)
         n0 = audio.shape[-1] - (seg - 1)                 # rf + 1 prologue positions
-        lp_buf = torch.zeros(B, 1, lpc) if lpc > 0 else None
+        lp_buf = audio[:, :, seg - 1:][:, :, -lpc:].clone() if lpc > 0 else None      # :317-319
 
         # lifted sample history, preallocated: prologue part then one slot per new sample
         lifted0 = _lift(cfg, P, audio)
@@ -334,8 +338,9 @@ def categorical_from_noise(logits: torch.Tensor, q: torch.Tensor):
 
 
 def softmax_generate(cfg, P, aux: torch.Tensor, n_samples_list: Sequence[int], noise,
-                     seed_index: Optional[int] = None, return_heads: bool = False):
-    """DSWNV.batch_fast_generate with seed audio (B,1) = encode_mu_law(0) = Q//2."""
+                     seed_index: Optional[int] = None, return_heads: bool = False, seed=None):
+    """DSWNV.batch_fast_generate; `seed` = its `audio` argument (B,) of classes (or one class `seed_index` for all),
+    encode_mu_law(0) = Q//2 when None; the left padding is always class Q//2 (dswnv.py:308)."""
     K, L, Q = cfg.K, cfg.L, cfg.n_quantize
     B = aux.shape[0]
     rf = cfg.receptive_field
@@ -345,7 +350,7 @@ def softmax_generate(cfg, P, aux: torch.Tensor, n_samples_list: Sequence[int], n
     with torch.no_grad():
         x = F.pad(upsample(cfg, P, frontend(cfg, P, aux)), (rf, 0), "replicate")
         audio = torch.full((B, rf + 1), Q // 2, dtype=torch.int64)
-        audio[:, -1] = seed_index
+        audio[:, -1] = seed_index if seed is None else torch.as_tensor(seed, dtype=torch.int64).reshape(B)
         oh = one_hot(audio, Q).transpose(1, 2)                          # B,Q,rf+1
         x0 = x[:, :, : oh.shape[2]]
         if cfg.audio_in_flag:
@@ -400,3 +405,38 @@ def laplace_nll(mu, b, target, log_b=None):
     if log_b is None:
         log_b = torch.log(b)
     return torch.mean(0.69314718055994530941723212145818 + log_b + torch.abs(target - mu) / b)
+
+
+# --------------------------------------------------------------------------- in-kernel noise generator (restated)
+def philox4x32_10(counter, key):
+    """Philox4x32-10 (Salmon et al., SC'11) on numpy uint32 arrays: counter (..., 4), key (2,) -> (..., 4).
+    Restates csrc/swn_noise.hpp::swn_philox4x32_10; checked against the Random123 known-answer vectors in
+    tests/test_oracle_golden.py."""
+    c = np.array(counter, dtype=np.uint64, copy=True) & 0xFFFFFFFF
+    k0, k1 = np.uint64(int(key[0]) & 0xFFFFFFFF), np.uint64(int(key[1]) & 0xFFFFFFFF)
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[..., 0], M1 * c[..., 2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c = np.stack([(hi1 ^ c[..., 1] ^ k0) & mask, lo1, (hi0 ^ c[..., 3] ^ k1) & mask, lo0], axis=-1)
+        k0, k1 = (k0 + W0) & mask, (k1 + W1) & mask
+    return c.astype(np.uint32)
+
+
+def device_noise(kind: str, rng_seed: int, utt0: int, batch: int, n_steps: int, width: int) -> np.ndarray:
+    """the noise the decode kernels draw themselves (noise_dev == NULL): (B, n_steps, width) float32.
+    laplace: e = min(fma(0.9999, u24, -0.4999), 0.49999997), u24 = (word >> 8) * 2^-24 ;
+    softmax: q = -log(((word >> 9) + 0.5) * 2^-23)   (compare to ~1e-6 relative: the device logf is not libm's)."""
+    tag = 0x4C41504C if kind == "laplace" else 0x45585031
+    b, s, e = np.meshgrid(np.arange(batch, dtype=np.uint64), np.arange(n_steps, dtype=np.uint64),
+                          np.arange(width, dtype=np.uint64), indexing="ij")
+    ctr = np.stack([(b + np.uint64(utt0)) & np.uint64(0xFFFFFFFF), s, e >> np.uint64(2), np.full_like(e, tag)], axis=-1)
+    words = philox4x32_10(ctr, (rng_seed & 0xFFFFFFFF, (rng_seed >> 32) & 0xFFFFFFFF))
+    w = np.take_along_axis(words, (e & np.uint64(3)).astype(np.int64)[..., None], axis=-1)[..., 0]
+    if kind == "laplace":
+        u = (w >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+        v = (np.float64(np.float32(0.9999)) * u.astype(np.float64) + np.float64(np.float32(-0.4999))).astype(np.float32)   # one rounding, like fmaf
+        return np.minimum(v, np.float32(0.49999997))
+    u = ((w >> np.uint32(9)).astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -23)
+    return (-np.log(u.astype(np.float64))).astype(np.float32)

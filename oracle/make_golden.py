@@ -227,6 +227,51 @@ def gen_teacher_forced(name, cfg, frames, wseed, flavor, aux_seed):
     print(f"[golden] {name}: B={B} T={T} rf={cfg.receptive_field} loss={loss.item():.5f} {time.time() - t0:.1f}s")
 
 
+def gen_seeded(name, cfg, frames, wseed, flavor, aux_seed, noise_seed):
+    """G8: `batch_fast_generate` of the reference with a NON-ZERO seed waveform / seed class (its `audio` argument)."""
+    t0 = time.time()
+    m, sd = build_ref(cfg, wseed, flavor)
+    aux = ragged_aux(cfg, frames, aux_seed)
+    n_samples = [f * cfg.U for f in frames]
+    B = len(frames)
+    rng = np.random.Generator(np.random.PCG64([aux_seed, 31]))
+    out = dict(cfg_json=np.array(repr(cfg.to_dict())), wseed=wseed, flavor=np.array(flavor), frames=np.array(frames),
+               aux=aux, noise_seed=noise_seed, n_samples=np.array(n_samples))
+    if cfg.kind == "laplace":
+        seed = rng.uniform(-0.8, 0.8, size=(B, cfg.seg)).astype(np.float32)
+        rec = []
+        orig_uniform = torch.Tensor.uniform_
+
+        def rec_uniform(self, *a, **k):
+            r = orig_uniform(self, *a, **k)
+            rec.append(self.detach().clone())
+            return r
+
+        torch.manual_seed(noise_seed)
+        torch.Tensor.uniform_ = rec_uniform
+        try:
+            samples = m.batch_fast_generate(torch.from_numpy(seed), torch.from_numpy(aux), n_samples, 4410)
+        finally:
+            torch.Tensor.uniform_ = orig_uniform
+        n_steps = max(n_samples) // cfg.seg
+        noise = (torch.stack(rec).reshape(n_steps, cfg.seg, B).permute(0, 2, 1) if cfg.lpc > 0
+                 else torch.stack(rec).reshape(n_steps, B, cfg.seg)).contiguous().numpy()
+        out["noise"] = noise
+        for b in range(B):
+            out[f"samples_{b}"] = samples[b].astype(np.float32)
+    else:
+        seed = rng.integers(0, cfg.n_quantize, size=(B, 1)).astype(np.int64)
+        torch.manual_seed(noise_seed)
+        samples = m.batch_fast_generate(torch.from_numpy(seed), torch.from_numpy(aux), n_samples, 4410)
+        g = torch.Generator().manual_seed(noise_seed)
+        out["q"] = cpu_ref.softmax_noise(cfg, max(n_samples), B, generator=g)
+        for b in range(B):
+            out[f"samples_{b}"] = samples[b].astype(np.int64)
+    out["seed"] = seed
+    np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
+    print(f"[golden] {name}: B={B} seed={seed.ravel()[:4]} {time.time() - t0:.1f}s")
+
+
 def gen_softmax(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, head_stride=1,
                 with_forward=True, with_grads=False):
     t0 = time.time()
@@ -548,6 +593,18 @@ def main():
     jobs.append(("g0_tiny_softmax_wav", gen_softmax,
                  dict(cfg=C.tiny("softmax", wav_conv_flag=True), frames=[8, 6], wseed=14,
                       flavor="xavier", aux_seed=3, noise_seed=8, with_grads=False)))
+    # ---- G8: non-zero seed waveform / seed class handed to batch_fast_generate
+    jobs.append(("g8_seed_laplace_s5l4", gen_seeded,
+                 dict(cfg=C.tiny("laplace", 5, 4), frames=[6, 5], wseed=61, flavor="trained", aux_seed=9, noise_seed=21)))
+    jobs.append(("g8_seed_laplace_s1l4", gen_seeded,
+                 dict(cfg=C.tiny("laplace", 1, 4), frames=[6, 5], wseed=62, flavor="trained", aux_seed=9, noise_seed=22)))
+    jobs.append(("g8_seed_laplace_bl6_s2l4", gen_seeded,
+                 dict(cfg=C.bl6_laplace(2, 4), frames=[3, 2], wseed=63, flavor="trained", aux_seed=9, noise_seed=23)))
+    jobs.append(("g8_seed_smx", gen_seeded,
+                 dict(cfg=C.tiny("softmax", wav_conv_flag=False), frames=[6, 5], wseed=64, flavor="xavier", aux_seed=9,
+                      noise_seed=24)))
+    jobs.append(("g8_seed_smx_bl6", gen_seeded,
+                 dict(cfg=C.bl6_softmax(), frames=[3, 2], wseed=65, flavor="xavier", aux_seed=9, noise_seed=25)))
     # ---- G1 BL6 (BASELINE-literal)
     for fl in ("xavier", "trained"):
         jobs.append((f"g1_bl6_lap_s1l0_b1_{fl}", gen_laplace,

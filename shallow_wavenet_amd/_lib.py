@@ -29,6 +29,15 @@ class NetDesc(ctypes.Structure):
         "n_quantize", "wav_conv_flag", "audio_in_flag", "aux_conv2d_flag")]
 
 
+class DecodeIO(ctypes.Structure):
+    """mirror of `swn_decode_io` (include/swn_hip.h): inputs of the sampling loop."""
+    _fields_ = [("noise_dev", c_void_p), ("forced_dev", c_void_p), ("seed_dev", c_void_p), ("noise_out_dev", c_void_p),
+                ("rng_seed", ctypes.c_uint64), ("rng_utt0", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+ABI_VERSION = 2
+
+
 def desc_from_cfg(cfg: NetConfig) -> NetDesc:
     soft = cfg.kind == "softmax"
     return NetDesc(kind=1 if soft else 0, n_aux=cfg.n_aux, hid_chn=cfg.hid_chn, skip_chn=cfg.skip_chn,
@@ -57,7 +66,7 @@ SIGNATURES = {
     "swn_cond_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_frontend": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "swn_decode_state_floats": (c_size_t, [POINTER(NetDesc), c_int]),
-    "swn_decode": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
+    "swn_decode": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_int, POINTER(DecodeIO),
                            c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "swn_forward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p,
@@ -117,7 +126,7 @@ def lib() -> ctypes.CDLL:
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
-        if l.swn_abi_version() != 1:
+        if l.swn_abi_version() != ABI_VERSION:
             raise RuntimeError("shallow_wavenet_amd: ABI version mismatch")
         _lib = l
         return l

@@ -16,7 +16,7 @@
 // rings: a slot that would hold a negative position has not been written yet.
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
-#include <cstdlib>
+#include "swn_noise.hpp"
 
 namespace {
 
@@ -27,8 +27,9 @@ struct DecArgs {
     SwnLayout y;
     const float* packed;
     const float* cond;
-    const float* noise;
+    SwnNoise nz;
     const void* forced;
+    const void* seed;
     float* state;
     void* out;
     float* heads;
@@ -114,9 +115,14 @@ __global__ __launch_bounds__(NT) void decode_generic_kernel(const DecArgs a) {
     const int lds_floats = (int)((tf + SEGT * SEGT) - reinterpret_cast<int*>(smem));
     for (int e = tid; e < lds_floats; e += NT) smem[e] = 0.f;
     int* ihist = reinterpret_cast<int*>(shist);
+    __syncthreads();
     if (KIND == SWN_KIND_SOFTMAX) {
-        __syncthreads();
-        for (int e = tid; e < WN; e += NT) ihist[e] = g.Q / 2;   // seed = encode_mu_law(0), dswnv.py:308
+        // padding class Q/2 = encode_mu_law(0), dswnv.py:308; the newest slot is the caller's seed class
+        const int sc = a.seed ? reinterpret_cast<const int*>(a.seed)[b] : g.Q / 2;
+        for (int e = tid; e < WN; e += NT) ihist[e] = (e == WN - 1) ? sc : g.Q / 2;
+    } else if (a.seed) {
+        // seed waveform `audio` (B, seg): the newest seg samples of the window (cswnv_shift1.py:300-334)
+        for (int e = tid; e < seg; e += NT) shist[WN - seg + e] = reinterpret_cast<const float*>(a.seed)[(size_t)b * seg + e];
     }
     __syncthreads();
 
@@ -226,7 +232,6 @@ __global__ __launch_bounds__(NT) void decode_generic_kernel(const DecArgs a) {
             // one uniform draw per sample, clamp before feedback.
             if (tid == 0) {
 #pragma clang fp contract(off)
-                const float* nz = a.noise + ((size_t)b * a.n_steps + i) * seg;
                 const float* forced = reinterpret_cast<const float*>(a.forced);
                 float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * seg + (size_t)i * seg;
                 float lp[16];
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(NT) void decode_generic_kernel(const DecArgs a) {
                     const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
                     float lpv = 0.f;
                     for (int k = 0; k < lpc; ++k) lpv += o2v[2 * seg + lpc - 1 - k] * lp[k];
-                    const float e = nz[j];
+                    const float e = swn_noise_laplace(a.nz, b, i, j, a.n_steps, seg);
                     const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
                     const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
                     float sv = (lpc > 0) ? (lpv + mu) - t : mu - t;
@@ -258,7 +263,6 @@ __global__ __launch_bounds__(NT) void decode_generic_kernel(const DecArgs a) {
             // multinomial(n=1) == argmax(p / q) with q ~ Exp(1) supplied by the host.
             if (tid < 64) {
                 const int Q = g.Q;
-                const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
                 float m = -INFINITY;
                 for (int e = tid; e < Q; e += 64) m = fmaxf(m, o2v[e]);
                 for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
@@ -270,7 +274,7 @@ __global__ __launch_bounds__(NT) void decode_generic_kernel(const DecArgs a) {
                 for (int d = 32; d >= 1; d >>= 1) sum2 += __shfl_xor(sum2, d, 64);
                 float best = -1.f; int bi = 0x7fffffff;
                 for (int e = tid; e < Q; e += 64) {
-                    const float r = ((expf(o2v[e] - m) / sum) / sum2) / qn[e];
+                    const float r = ((expf(o2v[e] - m) / sum) / sum2) / swn_noise_exp1(a.nz, b, i, e, a.n_steps, Q);
                     if (r > best) { best = r; bi = e; }
                 }
                 for (int d = 32; d >= 1; d >>= 1) {
@@ -313,20 +317,20 @@ int ring_plan(const SwnGeom& g, int* off, int* len) {
 
 // defined in swn_decode_bl6.hip; returns SWN_E_UNSUPPORTED when the geometry is not a BL6-class one
 extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, const float* cond,
-                                  int batch, int n_frames, int n_steps, const float* noise,
-                                  const void* forced, void* out, float* heads, void* stream);
+                                  int batch, int n_frames, int n_steps, const SwnNoise* nz,
+                                  const void* forced, const void* seed, void* out, float* heads, void* stream);
 
 // defined in swn_decode_stepped.hip
 extern "C" size_t swn_decode_stepped_state_floats(const swn_net_desc* d, int batch);
 extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
-                                  int n_steps, const float* noise, const void* forced, float* state, void* out,
-                                  float* heads, void* stream);
+                                  int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
+                                  void* out, float* heads, void* stream);
 
 // defined in swn_decode_cohort.hip
 extern "C" size_t swn_decode_cohort_state_floats(const swn_net_desc* d, int batch);
 extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
-                                 int n_steps, const float* noise, const void* forced, float* state, void* out,
-                                 float* heads, void* stream);
+                                 int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
+                                 void* out, float* heads, void* stream);
 
 extern "C" size_t swn_decode_state_floats(const swn_net_desc* d, int batch) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1) return 0;
@@ -338,38 +342,38 @@ extern "C" size_t swn_decode_state_floats(const swn_net_desc* d, int batch) {
 }
 
 extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const float* cond, int batch,
-                          int n_frames, int n_steps, const float* noise, const void* forced,
+                          int n_frames, int n_steps, const swn_decode_io* io,
                           float* state, void* out, float* heads, int variant, void* stream_) {
     DecArgs a;
     int rc = swn_make_geom(d, &a.g);
     if (rc < 0) return rc;
-    if (batch < 1 || n_frames < 1 || n_steps < 0) return SWN_E_BADARG;
+    if (batch < 1 || n_frames < 1 || n_steps < 0 || !io) return SWN_E_BADARG;
     if (n_steps == 0) return SWN_OK;                       // nothing to generate (empty buffers may be null)
-    if (!packed || !cond || !noise || !out) return SWN_E_BADARG;
+    if (!packed || !cond || !out) return SWN_E_BADARG;
     if ((long)n_steps * a.g.seg > (long)n_frames * a.g.U) return SWN_E_BADARG;   // conditioning too short
+    SwnNoise nz;
+    nz.ptr = io->noise_dev; nz.dump = io->noise_out_dev;
+    nz.key0 = (uint32_t)(io->rng_seed & 0xffffffffu); nz.key1 = (uint32_t)(io->rng_seed >> 32); nz.utt0 = io->rng_utt0;
+    const void* forced = io->forced_dev;
+    const void* seed = io->seed_dev;
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls
     if (variant == 0 || variant == 2) {
-        rc = swn_decode_bl6_try(d, packed, cond, batch, n_frames, n_steps, noise, forced, out, heads, stream_);
+        rc = swn_decode_bl6_try(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, out, heads, stream_);
         if (rc != SWN_E_UNSUPPORTED || variant == 2) return rc;
     }
     if (!state) return SWN_E_BADARG;
     // large geometries (REF6: MBs of weights per step) run one launch per phase over many CUs
     const bool big = (size_t)a.g.L * 2 * a.g.H * a.g.K * a.g.Hp >= (size_t)256 * 1024;
-    // variant 4 (cohort: lanes = utterances, weights cross the chip once per step and cohort) only ties the stepped
-    // decode so far (REF6 Laplace B=64: 161 us/step both; softmax 226 vs 268), so auto does not pick it unless
-    // SWN_COHORT_MIN=<utterances> asks for it
-    const char* cm = getenv("SWN_COHORT_MIN");
-    if (variant == 4 || (variant == 0 && big && cm && batch >= atoi(cm))) {
-        rc = swn_decode_cohort(d, packed, cond, batch, n_frames, n_steps, noise, forced, state, out, heads, stream_);
-        if (rc != SWN_E_UNSUPPORTED || variant == 4) return rc;
-    }
+    // variant 4 (cohort: lanes = utterances, weights cross the chip once per step and cohort) is explicit only: it ties
+    // the stepped decode at best (REF6 Laplace B=64: 161 us/step both; softmax 226 vs 268)
+    if (variant == 4) return swn_decode_cohort(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, state, out, heads, stream_);
     if (variant == 3 || (variant == 0 && big)) {
-        rc = swn_decode_stepped(d, packed, cond, batch, n_frames, n_steps, noise, forced, state, out, heads, stream_);
+        rc = swn_decode_stepped(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, state, out, heads, stream_);
         if (rc != SWN_E_UNSUPPORTED || variant == 3) return rc;
     }
     swn_make_layout(&a.g, &a.y);
-    a.packed = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state;
+    a.packed = packed; a.cond = cond; a.nz = nz; a.forced = forced; a.seed = seed; a.state = state;
     a.out = out; a.heads = heads; a.B = batch; a.Tf = n_frames; a.n_steps = n_steps;
     a.state_stride = ring_plan(a.g, a.ring_off, a.ring_len);
     if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.state_stride * batch, st) != hipSuccess)

@@ -18,6 +18,7 @@
 // 9 s_barriers per generated step (10 for softmax).
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
+#include "swn_noise.hpp"
 
 namespace {
 
@@ -35,8 +36,9 @@ struct B6Args {
     const float* P;
     SwnLayout y;
     const float* cond;
-    const float* noise;
+    SwnNoise nz;
     const void* forced;
+    const void* seed;
     void* out;
     float* heads;
     int B, Tf, n_steps, U, N;
@@ -436,6 +438,14 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     for (int k = 0; k < WNF; ++k) win[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < WNI; ++k) iwin[k] = T::Q / 2;
+    if (a.seed) {       // seed waveform `audio` of batch_fast_generate: the newest SEG samples / the newest class
+        if constexpr (KIND == SWN_KIND_LAPLACE) {
+#pragma unroll
+            for (int j = 0; j < SEG; ++j) win[WNF - SEG + j] = reinterpret_cast<const float*>(a.seed)[(size_t)b * SEG + j];
+        } else {
+            iwin[WNI - 1] = reinterpret_cast<const int*>(a.seed)[b];
+        }
+    }
     auto input_gen = [&](int q0n) {
         if (tid < H) {
             const int o = tid;
@@ -466,11 +476,11 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                 const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
                 lds[T::o_tnz + (step & 1) * 8 + j] = sg * log1pf(-2.f * fabsf(e));
             }
-            if (step + 1 < a.n_steps) e_next = a.noise[((size_t)b * a.n_steps + step + 1) * SEG + j];
+            if (step + 1 < a.n_steps) e_next = swn_noise_laplace(a.nz, b, step + 1, j, a.n_steps, SEG);
         }
     };
     if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG && a.n_steps > 0)
-        e_next = a.noise[(size_t)b * a.n_steps * SEG + (tid - 64)];
+        e_next = swn_noise_laplace(a.nz, b, 0, tid - 64, a.n_steps, SEG);
 
     // ---- prologue: seed positions 0..rf-seg, one position per pass (cswnv_shift1.py:321-334)
 #pragma unroll 1
@@ -660,9 +670,8 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
             constexpr int QL = Q > 0 ? (Q + 63) / 64 : 1;     // classes per lane (this branch is also compiled for Laplace nets)
             float qv[QL];
             if (tid < 64) {
-                const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
 #pragma unroll
-                for (int k = 0; k < QL; ++k) qv[k] = tid + 64 * k < Q ? qn[tid + 64 * k] : 1.f;
+                for (int k = 0; k < QL; ++k) qv[k] = tid + 64 * k < Q ? swn_noise_exp1(a.nz, b, i, tid + 64 * k, a.n_steps, Q) : 1.f;
             }
             tiled_matvec<T::NO, T::O1>(w22, lds + T::o_bias + S + T::O1, lds + T::o_o1, lds + T::o_o2, false);
             lds_barrier();
@@ -729,14 +738,14 @@ int launch(const B6Args& a, hipStream_t st) {
 }  // namespace
 
 extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, const float* cond, int batch,
-                                  int n_frames, int n_steps, const float* noise, const void* forced,
-                                  void* out, float* heads, void* stream_) {
+                                  int n_frames, int n_steps, const SwnNoise* nz, const void* forced,
+                                  const void* seed, void* out, float* heads, void* stream_) {
     SwnGeom g; int rc = swn_make_geom(d, &g);
     if (rc < 0) return rc;
     if (!g.bl6 || g.U > 256 || g.U < 2 * g.seg || g.audio_in) return SWN_E_UNSUPPORTED;
     B6Args a;
     swn_make_layout(&g, &a.y);
-    a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.out = out; a.heads = heads;
+    a.P = packed; a.cond = cond; a.nz = *nz; a.forced = forced; a.seed = seed; a.out = out; a.heads = heads;
     a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.U = g.U; a.N = g.N;
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported

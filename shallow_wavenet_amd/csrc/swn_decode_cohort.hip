@@ -16,6 +16,7 @@
 // dswnv.py:338-374); only the order of the fp32 sums over the inputs differs (16 contiguous slices).
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
+#include "swn_noise.hpp"
 #include <type_traits>
 
 namespace {
@@ -35,7 +36,7 @@ __device__ __forceinline__ float co_ld1(__amdgpu_buffer_rsrc_t r, unsigned off) 
 struct CoArgs {
     SwnGeom g;
     SwnLayout y;
-    const float* P; const float* cond; const float* noise; const void* forced;
+    const float* P; const float* cond; SwnNoise nz; const void* forced; const void* seed;
     float* state; void* out; float* heads;
     int B, Tf, n_steps, n_pro, WN;
     int ring_off[SWN_MAXL], ring_len[SWN_MAXL];
@@ -285,7 +286,6 @@ __global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int 
         {
 #pragma clang fp contract(off)
         // Laplace head, cswnv_shift1.py:368-391
-        const float* nz = a.noise + ((size_t)b * a.n_steps + i) * seg;
         const float* forced = reinterpret_cast<const float*>(a.forced);
         float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * seg + (size_t)i * seg;
         float lp[16], fed[16];
@@ -296,7 +296,7 @@ __global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int 
             const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
             float lpv = 0.f;
             for (int k = 0; k < lpc; ++k) lpv += o2[(size_t)(2 * seg + lpc - 1 - k) * CO] * lp[k];
-            const float e = nz[j];
+            const float e = swn_noise_laplace(a.nz, b, i, j, a.n_steps, seg);
             const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
             const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
             float sv = (lpc > 0) ? (lpv + mu) - t : mu - t;
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int 
     } else {
         // softmax head, dswnv.py:361-369: p = softmax(logits); p /= sum(p); index = argmax(p / q), q ~ Exp(1)
         const int Q = g.Q, e0 = w * ((Q + 3) / 4), e1 = (e0 + (Q + 3) / 4 < Q) ? e0 + (Q + 3) / 4 : Q;
-        const float* qn = a.noise + ((size_t)(live ? b : 0) * a.n_steps + i) * Q;
+        const int bq = live ? b : 0;
         float m = -INFINITY;
         for (int e = e0; e < e1; ++e) m = fmaxf(m, o2[(size_t)e * CO]);
         redf[w][lane] = m; __syncthreads();
@@ -328,7 +328,7 @@ __global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int 
         sum2 = (redf[0][lane] + redf[1][lane]) + (redf[2][lane] + redf[3][lane]); __syncthreads();
         float best = -1.f; int bi = 0x7fffffff;
         for (int e = e0; e < e1; ++e) {
-            const float rr = ((expf(o2[(size_t)e * CO] - m) / sum) / sum2) / qn[e];
+            const float rr = ((expf(o2[(size_t)e * CO] - m) / sum) / sum2) / swn_noise_exp1(a.nz, bq, i, e, a.n_steps, Q);
             if (rr > best) { best = rr; bi = e; }
         }
         redf[w][lane] = best; redi[w][lane] = bi; __syncthreads();
@@ -346,11 +346,19 @@ __global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int 
     }
 }
 
-// softmax: the sample window starts as the mu-law zero class
+// sample window after the state was zeroed: softmax = padding class Q/2 with the caller's seed class newest;
+// Laplace = the caller's seed samples in the newest seg slots
 __global__ void co_seed_kernel(const CoArgs a) {
-    const int c = blockIdx.x, lane = threadIdx.x;
+    const int c = blockIdx.x, lane = threadIdx.x, b = c * CO + lane;
     float* st = a.state + (size_t)c * a.stride * CO + lane;
-    for (int k = 0; k < a.WN; ++k) st[(size_t)(a.o_hist + k) * CO] = __builtin_bit_cast(float, a.g.Q / 2);
+    const bool live = b < a.B;
+    if (a.g.kind == SWN_KIND_SOFTMAX) {
+        const int sc = (a.seed && live) ? reinterpret_cast<const int*>(a.seed)[b] : a.g.Q / 2;
+        for (int k = 0; k < a.WN; ++k) st[(size_t)(a.o_hist + k) * CO] = __builtin_bit_cast(float, k == a.WN - 1 ? sc : a.g.Q / 2);
+    } else if (a.seed && live) {
+        for (int j = 0; j < a.g.seg; ++j)
+            st[(size_t)(a.o_hist + a.WN - a.g.seg + j) * CO] = reinterpret_cast<const float*>(a.seed)[(size_t)b * a.g.seg + j];
+    }
 }
 
 int plan(CoArgs& a) {
@@ -376,8 +384,8 @@ extern "C" size_t swn_decode_cohort_state_floats(const swn_net_desc* d, int batc
 }
 
 extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
-                                 int n_steps, const float* noise, const void* forced, float* state, void* out,
-                                 float* heads, void* stream_) {
+                                 int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
+                                 void* out, float* heads, void* stream_) {
     CoArgs a;
     int rc = swn_make_geom(d, &a.g);
     if (rc < 0) return rc;
@@ -386,13 +394,13 @@ extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, con
     if (!state) return SWN_E_BADARG;
     swn_make_layout(&a.g, &a.y);
     plan(a);
-    a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state; a.out = out; a.heads = heads;
+    a.P = packed; a.cond = cond; a.nz = *nz; a.forced = forced; a.seed = seed; a.state = state; a.out = out; a.heads = heads;
     a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.n_pro = g.rf - g.seg + 1;
     hipStream_t st = (hipStream_t)stream_;
     const unsigned nco = (unsigned)((batch + CO - 1) / CO);
     if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.stride * CO * nco, st) != hipSuccess) return SWN_E_LAUNCH;
     const bool lap = g.kind == SWN_KIND_LAPLACE;
-    if (!lap) hipLaunchKernelGGL(co_seed_kernel, dim3(nco), dim3(CO), 0, st, a);
+    if (!lap || seed) hipLaunchKernelGGL(co_seed_kernel, dim3(nco), dim3(CO), 0, st, a);
     // slice width per wave and tap (multiple of 4); the instantiated widths cover Hp <= 256 and K <= 8
     const int ipw = ((g.Hp + KS - 1) / KS + 3) & ~3;
     if ((ipw != 4 && ipw != 12 && ipw != 16) || g.K > 8) return SWN_E_UNSUPPORTED;

@@ -16,14 +16,14 @@
 // and the ring layout are those of the generic persistent kernel (swn_decode.hip).
 #include <hip/hip_runtime.h>
 #include "swn_geom.hpp"
-#include <cstdlib>
+#include "swn_noise.hpp"
 
 namespace {
 
 struct StArgs {
     SwnGeom g;
     SwnLayout y;
-    const float* P; const float* cond; const float* noise; const void* forced;
+    const float* P; const float* cond; SwnNoise nz; const void* forced; const void* seed;
     float* state; void* out; float* heads;
     int B, Tf, n_steps, n_pro, WN;
     int ring_off[SWN_MAXL], ring_len[SWN_MAXL];
@@ -296,7 +296,6 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
         if (tid == 0) {
 #pragma clang fp contract(off)
             // Laplace head, cswnv_shift1.py:368-391
-            const float* nz = a.noise + ((size_t)b * a.n_steps + i) * seg;
             const float* forced = reinterpret_cast<const float*>(a.forced);
             float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * seg + (size_t)i * seg;
             float lp[16], fed[16];
@@ -307,7 +306,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
                 const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
                 float lpv = 0.f;
                 for (int k = 0; k < lpc; ++k) lpv += o2v[2 * seg + lpc - 1 - k] * lp[k];
-                const float e = nz[j];
+                const float e = swn_noise_laplace(a.nz, b, i, j, a.n_steps, seg);
                 const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
                 const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
                 float sv = (lpc > 0) ? (lpv + mu) - t : mu - t;
@@ -324,7 +323,6 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
     } else if (tid < 64) {
         // softmax head, dswnv.py:361-369
         const int Q = g.Q;
-        const float* qn = a.noise + ((size_t)b * a.n_steps + i) * Q;
         float m = -INFINITY;
         for (int e = tid; e < Q; e += 64) m = fmaxf(m, o2v[e]);
         for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
@@ -336,7 +334,7 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
         for (int d = 32; d >= 1; d >>= 1) sum2 += __shfl_xor(sum2, d, 64);
         float best = -1.f; int bi = 0x7fffffff;
         for (int e = tid; e < Q; e += 64) {
-            const float r = ((expf(o2v[e] - m) / sum) / sum2) / qn[e];
+            const float r = ((expf(o2v[e] - m) / sum) / sum2) / swn_noise_exp1(a.nz, b, i, e, a.n_steps, Q);
             if (r > best) { best = r; bi = e; }
         }
         for (int d = 32; d >= 1; d >>= 1) {
@@ -358,11 +356,18 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
     if (i + 1 < a.n_steps) input_layer<KIND>(a, st, it + 1, tid, 256, lwin);
 }
 
-// set the sample window seed (softmax: mu-law zero class) after the state was zeroed
+// set the sample window after the state was zeroed: softmax = padding class Q/2 (dswnv.py:308) with the caller's seed
+// class in the newest slot; Laplace = the caller's seed samples in the newest seg slots (cswnv_shift1.py:300-334)
 __global__ void step_seed_kernel(const StArgs a) {
-    const int b = blockIdx.x;
-    int* ihist = reinterpret_cast<int*>(a.state + (size_t)b * a.stride + a.o_hist);
-    if ((int)threadIdx.x < a.WN) ihist[threadIdx.x] = a.g.Q / 2;
+    const int b = blockIdx.x, k = threadIdx.x;
+    float* hist = a.state + (size_t)b * a.stride + a.o_hist;
+    if (k >= a.WN) return;
+    if (a.g.kind == SWN_KIND_SOFTMAX) {
+        const int sc = a.seed ? reinterpret_cast<const int*>(a.seed)[b] : a.g.Q / 2;
+        reinterpret_cast<int*>(hist)[k] = (k == a.WN - 1) ? sc : a.g.Q / 2;
+    } else if (a.seed && k >= a.WN - a.g.seg) {
+        hist[k] = reinterpret_cast<const float*>(a.seed)[(size_t)b * a.g.seg + (k - (a.WN - a.g.seg))];
+    }
 }
 
 int plan(StArgs& a) {
@@ -389,8 +394,8 @@ extern "C" size_t swn_decode_stepped_state_floats(const swn_net_desc* d, int bat
 }
 
 extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
-                                  int n_steps, const float* noise, const void* forced, float* state, void* out,
-                                  float* heads, void* stream_) {
+                                  int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
+                                  void* out, float* heads, void* stream_) {
     StArgs a;
     int rc = swn_make_geom(d, &a.g);
     if (rc < 0) return rc;
@@ -400,16 +405,15 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     { StArgs t; t.g = a.g; if ((size_t)plan(t) * batch * sizeof(float) >= (1ull << 31) || t.WN > 32) return SWN_E_UNSUPPORTED; }   // 32-bit buffer offsets; LDS window
     swn_make_layout(&a.g, &a.y);
     plan(a);
-    a.P = packed; a.cond = cond; a.noise = noise; a.forced = forced; a.state = state; a.out = out; a.heads = heads;
+    a.P = packed; a.cond = cond; a.nz = *nz; a.forced = forced; a.seed = seed; a.state = state; a.out = out; a.heads = heads;
     a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.n_pro = g.rf - g.seg + 1;
     hipStream_t st = (hipStream_t)stream_;
     if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.stride * batch, st) != hipSuccess) return SWN_E_LAUNCH;
-    if (g.kind == SWN_KIND_SOFTMAX) hipLaunchKernelGGL(step_seed_kernel, dim3(batch), dim3(64), 0, st, a);
+    if (g.kind == SWN_KIND_SOFTMAX || seed) hipLaunchKernelGGL(step_seed_kernel, dim3(batch), dim3(64), 0, st, a);
     // up to 64 utterances: one utterance per workgroup (weights re-read per utterance from the Infinity Cache;
     // measured faster than sharing: B=8 63 vs 137 us/step, B=64 162 vs 182 us/step on REF6);
     // otherwise tiles of 8 utterances share one weight fetch and are processed concurrently
-    const char* solo_env = getenv("SWN_STEPPED_SOLO_MAX");      // tuning knob, default from measurements
-    const bool solo = batch <= (solo_env ? atoi(solo_env) : 64);
+    const bool solo = batch <= 64;
     const unsigned by = solo ? (unsigned)batch : (unsigned)((batch + 7) / 8);
 #define SWN_LAYER(NI_, KIND_)                                                                                  \
     do {                                                                                                        \

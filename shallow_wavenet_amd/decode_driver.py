@@ -147,6 +147,7 @@ def gpu_decode(kind: str, args, config, feat_list: Sequence[str], device, packed
             packed = None
         model.to(device)
         model.eval()
+        model.noise_source = getattr(args, "noise_source", None)
         model.set_packed_engine(HipNet(cfg, D.broadcast_packed(cfg, packed, device, src=packed_src_rank), device))
         string_path = getattr(config, "string_path", "/feat_org_lf0")
         t_total, n_max, n_tot = 0.0, 0, 0
@@ -191,6 +192,10 @@ def make_parser() -> argparse.ArgumentParser:
     p.add_argument("--GPU_device", default=0, type=int, help="selection of GPU device")
     p.add_argument("--GPU_device_str", default=None, type=str, help="selection of GPU device")
     p.add_argument("--verbose", default=1, type=int, help="log level")
+    p.add_argument("--noise_source", default=None, choices=["host", "device"],
+                   help="not a reference flag: where the sampling noise is drawn - host = the torch CPU generator in "
+                        "the reference's order (reproduces the reference's CPU decode), device = inside the kernels; "
+                        "default: the model's own default (Laplace host, softmax device)")
     return p
 
 

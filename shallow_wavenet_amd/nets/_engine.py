@@ -109,6 +109,17 @@ class EngineMixin:
         self.__dict__["_engine_cache"] = (self._engine_key(), net)
 
 
+NOISE_SOURCES = ("host", "device")
+
+
+def resolve_noise_source(module, default: str) -> str:
+    """`module.noise_source`: "host" | "device" | None (= the model's default)."""
+    src = getattr(module, "noise_source", None) or default
+    if src not in NOISE_SOURCES:
+        raise ValueError(f"noise_source must be one of {NOISE_SOURCES} or None, not {src!r}")
+    return src
+
+
 def log_decode_speed(seg: int, n_steps: int, n_utts: int, seconds: float) -> None:
     """the two summary lines of the reference loop (cswnv_shift1.py:417-422 / dswnv.py:386-391);
     per-step times are not observable from inside one persistent launch, so the mean is used."""

@@ -33,7 +33,7 @@ if _PKG_PARENT not in sys.path:            # importable as top-level `cswnv_shif
 from shallow_wavenet_amd.config import NetConfig                      # noqa: E402
 from shallow_wavenet_amd import noise as _noise                       # noqa: E402
 from shallow_wavenet_amd.nets._engine import (                        # noqa: E402,F401
-    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, initialize, log_decode_speed)
+    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, initialize, log_decode_speed, resolve_noise_source)
 
 
 class CSWNV(EngineMixin, nn.Module):
@@ -140,20 +140,29 @@ class CSWNV(EngineMixin, nn.Module):
 
     # ------------------------------------------------------------------ autoregressive decode
     def batch_fast_generate(self, audio, aux, n_samples_list, intervals=4410, Laplace=True):
-        """audio (B, seg) seed waveform (zeros, decode_cswnv_laplace-shift1.py:93), aux
-        (B, n_aux, Tf) zero-padded features -> list of B float32 arrays trimmed to n_samples."""
+        """audio (B, seg) seed waveform (zeros in the decode driver, decode_cswnv_laplace-shift1.py:93; any values are
+        accepted, cswnv_shift1.py:300-334), aux (B, n_aux, Tf) zero-padded features -> list of B float32 arrays
+        trimmed to n_samples.
+
+        Noise (`self.noise_source`): "host" (default for this model) draws the uniform deviates with the torch CPU
+        generator in the reference's order, so `torch.manual_seed(s)` reproduces the reference's CPU decode sample for
+        sample; "device" lets the kernels draw them (keyed by one 63-bit value taken from the torch CPU generator, so
+        runs stay reproducible under `torch.manual_seed`), like the reference drawing on its model's device."""
         if not Laplace:
             raise NotImplementedError("the reference has no non-Laplace branch in this loop either")
-        if torch.count_nonzero(audio).item() != 0:
-            raise NotImplementedError("only the all-zero seed waveform of the decode driver is supported")
         with torch.no_grad():
             net = self._engine()
             B = aux.shape[0]
             max_samples = max(n_samples_list)
             n_steps = int(max_samples / self.seg) if self.seg > 1 else max_samples
-            noise = _noise.laplace_uniform(self._cfg, n_steps, B)      # host CPU generator, reference order
             start = time.time()
-            out, _ = net.decode(aux, n_steps, noise)
+            seed = audio.reshape(B, -1)[:, -self.seg:] if torch.count_nonzero(audio).item() != 0 else None
+            if resolve_noise_source(self, "host") == "host":
+                noise = _noise.laplace_uniform(self._cfg, n_steps, B)      # host CPU generator, reference order
+                out, _ = net.decode(aux, n_steps, noise, seed=seed)
+            else:
+                out, _ = net.decode(aux, n_steps, None, seed=seed, rng_seed=_noise.draw_rng_seed(),
+                                    rng_utt0=int(getattr(self, "noise_utterance_offset", 0)))
             samples = out.cpu().numpy()                                   # DEVICE -> HOST, :426
             log_decode_speed(self.seg, n_steps, len(n_samples_list), time.time() - start)
         samples = samples[:, -max_samples:] if max_samples <= samples.shape[1] else samples

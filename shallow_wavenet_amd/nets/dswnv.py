@@ -27,7 +27,7 @@ if _PKG_PARENT not in sys.path:
 from shallow_wavenet_amd.config import NetConfig                      # noqa: E402
 from shallow_wavenet_amd import noise as _noise                       # noqa: E402
 from shallow_wavenet_amd.nets._engine import (                        # noqa: E402,F401
-    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, initialize, log_decode_speed)
+    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, initialize, log_decode_speed, resolve_noise_source)
 
 
 def encode_mu_law(x, mu=256):
@@ -140,17 +140,27 @@ class DSWNV(EngineMixin, nn.Module):
         return raw.transpose(1, 2)
 
     def batch_fast_generate(self, audio, aux, n_samples_list, intervals=4410):
-        """audio (B, 1) seed class = encode_mu_law(0) (decode_dswnv_softmax.py:94-99), aux
-        (B, n_aux, Tf) -> list of B int64 class arrays trimmed to n_samples."""
-        if torch.count_nonzero(audio - self.n_quantize // 2).item() != 0:
-            raise NotImplementedError("only the mu-law zero seed of the decode driver is supported")
+        """audio (B, 1) seed class (encode_mu_law(0) = Q/2 in the decode driver, decode_dswnv_softmax.py:94-99; any
+        class is accepted, dswnv.py:305-336), aux (B, n_aux, Tf) -> list of B int64 class arrays trimmed to n_samples.
+
+        Noise (`self.noise_source`): "device" (default for this model) - the Exp(1) deviates of the categorical sampler
+        (dswnv.py:361-369) are drawn inside the kernels, keyed by one value taken from the torch CPU generator
+        (reproducible under `torch.manual_seed`), like the reference sampling on its model's device; "host" draws them
+        with the torch CPU generator in the reference's order - bit-exact indices against the reference's CPU decode,
+        at the price of B x n_steps x Q floats drawn, stored and uploaded by the host."""
         with torch.no_grad():
             net = self._engine()
             B = aux.shape[0]
             n_steps = max(n_samples_list)
-            noise = _noise.softmax_exponential(self._cfg, n_steps, B)     # Exp(1) draws of multinomial(n=1)
             start = time.time()
-            out, _ = net.decode(aux, n_steps, noise)
+            seed = audio.reshape(B, -1)[:, -1] % self.n_quantize
+            seed = seed if torch.count_nonzero(seed - self.n_quantize // 2).item() != 0 else None
+            if resolve_noise_source(self, "device") == "host":
+                noise = _noise.softmax_exponential(self._cfg, n_steps, B)     # Exp(1) draws of multinomial(n=1)
+                out, _ = net.decode(aux, n_steps, noise, seed=seed)
+            else:
+                out, _ = net.decode(aux, n_steps, None, seed=seed, rng_seed=_noise.draw_rng_seed(),
+                                    rng_utt0=int(getattr(self, "noise_utterance_offset", 0)))
             samples = out.cpu().numpy().astype(np.int64)
             log_decode_speed(1, n_steps, len(n_samples_list), time.time() - start)
         return [samples[b, :n] for b, n in zip(range(B), n_samples_list)]

@@ -160,13 +160,19 @@ class HipNet:
         return cond.view(B, Tf, -1)
 
     # ------------------------------------------------------------------ decode
-    def decode(self, aux: torch.Tensor, n_steps: int, noise: torch.Tensor,
+    def decode(self, aux: torch.Tensor, n_steps: int, noise: Optional[torch.Tensor] = None,
                forced: Optional[torch.Tensor] = None, want_heads: bool = False, variant: int = 0,
-               cond: Optional[torch.Tensor] = None):
+               cond: Optional[torch.Tensor] = None, seed: Optional[torch.Tensor] = None, rng_seed: int = 0,
+               rng_utt0: int = 0, want_noise: bool = False):
         """run prologue + n_steps generation steps for every utterance of the batch.
 
-        noise: laplace (B, n_steps, seg) | softmax (B, n_steps, Q), fp32, utterance-major.
-        returns (out, heads): out laplace (B, n_steps*seg) fp32 | softmax (B, n_steps) int32.
+        noise: laplace (B, n_steps, seg) | softmax (B, n_steps, Q), fp32, utterance-major - the host-drawn stream of
+               the parity mode; None = the kernels draw it themselves (counter-based generator keyed by `rng_seed`,
+               utterance b drawing as global utterance `rng_utt0 + b`).
+        seed:  the seed waveform `audio` of batch_fast_generate: laplace (B, seg) fp32 | softmax (B,) classes; None =
+               zeros / class Q/2.
+        returns (out, heads): out laplace (B, n_steps*seg) fp32 | softmax (B, n_steps) int32; with want_noise=True
+        a third value: the noise the kernels used, in the layout of `noise`.
         """
         cfg, L = self.cfg, self.lib
         soft = cfg.kind == "softmax"
@@ -175,21 +181,31 @@ class HipNet:
         B, Tf = cond.shape[0], cond.shape[1]
         seg = 1 if soft else cfg.seg
         width = cfg.n_quantize if soft else seg
-        noise = noise.to(self.device, torch.float32).contiguous()
-        if tuple(noise.shape) != (B, n_steps, width):
-            raise RuntimeError(f"noise shape {tuple(noise.shape)} != {(B, n_steps, width)}")
+        if noise is not None:
+            noise = noise.to(self.device, torch.float32).contiguous()
+            if tuple(noise.shape) != (B, n_steps, width):
+                raise RuntimeError(f"noise shape {tuple(noise.shape)} != {(B, n_steps, width)}")
         if forced is not None:
             forced = forced.to(self.device, torch.int32 if soft else torch.float32).contiguous()
             if forced.numel() != B * n_steps * seg:
                 raise RuntimeError("forced history has the wrong size")
+        if seed is not None:
+            seed = seed.to(self.device, torch.int32 if soft else torch.float32).contiguous()
+            if seed.numel() != B * seg:
+                raise RuntimeError(f"seed waveform has {seed.numel()} elements, expected {B * seg}")
         d = ctypes.byref(self.desc)
         state = torch.empty(L.swn_decode_state_floats(d, B), dtype=torch.float32, device=self.device)
         out = torch.empty((B, n_steps * seg), dtype=torch.int32 if soft else torch.float32, device=self.device)
         heads = torch.empty((B, n_steps, cfg.n_out), dtype=torch.float32, device=self.device) if want_heads else None
+        used = torch.empty((B, n_steps, width), dtype=torch.float32, device=self.device) if want_noise else None
+        io = _lib.DecodeIO(noise_dev=_ptr(noise), forced_dev=_ptr(forced), seed_dev=_ptr(seed), noise_out_dev=_ptr(used),
+                           rng_seed=int(rng_seed) & 0xFFFFFFFFFFFFFFFF, rng_utt0=int(rng_utt0) & 0xFFFFFFFF, reserved=0)
         with torch.cuda.device(self.device):
-            _lib.check(L.swn_decode(d, _ptr(self.packed), _ptr(cond), B, Tf, n_steps, _ptr(noise),
-                                    _ptr(forced), _ptr(state), _ptr(out), _ptr(heads), variant,
+            _lib.check(L.swn_decode(d, _ptr(self.packed), _ptr(cond), B, Tf, n_steps, ctypes.byref(io),
+                                    _ptr(state), _ptr(out), _ptr(heads), variant,
                                     _stream_ptr(self.device)), "decode")
+        if want_noise:
+            return out, heads, used
         return out, heads
 
     # ------------------------------------------------------------------ teacher-forced stack

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in _lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.swn_abi_version() == 1
+    assert lib.swn_abi_version() == 2
     assert lib.swn_strerror(-1).decode().startswith("network descriptor")
 
 

@@ -95,7 +95,8 @@ def test_driver_end_to_end_reproduces_the_reference_batch(gpu_ok, tmp_path, name
                           "decode_cswnv_laplace-shift1.py" if kind == "laplace" else "decode_dswnv_softmax.py")
     r = subprocess.run([sys.executable, script, "--feats", str(feats), "--checkpoint", str(tmp_path / "checkpoint-1.pkl"),
                         "--config", str(tmp_path / "model.json"), "--outdir", str(out), "--fs", "22050",
-                        "--batch_size", "2", "--seed", str(int(d["noise_seed"])), "--verbose", "1"],
+                        "--batch_size", "2", "--seed", str(int(d["noise_seed"])), "--verbose", "1",
+                        "--noise_source", "host"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "average throughput / sample" in r.stderr + open(out / "decode.log").read()

@@ -109,6 +109,7 @@ def test_dswnv_module_generate_bit_exact(gpu_ok, name):
     m = md.DSWNV(**cfg.ctor_kwargs())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in _sd(cfg, d).items()})
     m.cuda().eval()
+    m.noise_source = "host"          # parity mode: the reference's CPU Exp(1) stream (the model's default draws on the device)
     n_samples = [int(n) for n in d["n_samples"]]
     torch.manual_seed(int(d["noise_seed"]))
     out = m.batch_fast_generate(torch.full((len(n_samples), 1), cfg.n_quantize // 2, dtype=torch.int64).cuda(),

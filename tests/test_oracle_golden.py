@@ -262,3 +262,40 @@ def test_oracle_teacher_forced_ref6_forward_and_gradients(name):
     loss.backward()
     grads = {k: (P[k].grad.numpy() if P[k].grad is not None else np.zeros(tuple(P[k].shape), np.float32)) for k in P}
     check_grads_against_fixture(name, grads, d)
+
+
+def test_philox_restatement_known_answers():
+    """Random123's published Philox4x32-10 known-answer vectors (kat_vectors: counter, key -> output)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0),
+            (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = cpu_ref.philox4x32_10(np.array(ctr, dtype=np.uint32), key)
+        assert tuple(int(x) for x in got) == want
+    e = cpu_ref.device_noise("laplace", 0x1234567890ABCDEF, 3, 2, 5, 5)
+    assert e.shape == (2, 5, 5) and e.dtype == np.float32 and e.min() >= -0.4999 and e.max() < 0.5
+    q = cpu_ref.device_noise("softmax", 7, 0, 1, 3, 256)
+    assert q.shape == (1, 3, 256) and q.min() > 0 and abs(q.mean() - 1.0) < 0.2
+
+
+G8 = [n for n in golden_names() if n.startswith("g8_")]
+
+
+@pytest.mark.parametrize("name", G8)
+def test_oracle_generate_with_a_nonzero_seed_matches_the_reference(name):
+    """batch_fast_generate(audio != 0) of the reference (cswnv_shift1.py:300-334 / dswnv.py:305-336)."""
+    cfg, d = load_golden(name)
+    P = _params(cfg, d)
+    n_samples = [int(n) for n in d["n_samples"]]
+    aux = torch.from_numpy(d["aux"])
+    if cfg.kind == "laplace":
+        res = cpu_ref.laplace_generate(cfg, P, aux, n_samples, d["noise"], seed=d["seed"])
+        zero = cpu_ref.laplace_generate(cfg, P, aux, n_samples, d["noise"])
+        for b, n in enumerate(n_samples):
+            assert np.abs(res[b] - d[f"samples_{b}"]).max() <= TOL, (name, b)
+        assert np.abs(zero[0] - d["samples_0"]).max() > 1e-4           # the seed is not ignored
+    else:
+        res = cpu_ref.softmax_generate(cfg, P, aux, n_samples, d["q"], seed=d["seed"])
+        for b, n in enumerate(n_samples):
+            assert np.array_equal(res[b], d[f"samples_{b}"]), (name, b)
