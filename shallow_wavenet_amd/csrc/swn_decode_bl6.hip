@@ -36,21 +36,25 @@ struct B6Args {
     const float* P;
     SwnLayout y;
     const float* cond;
-    SwnNoise nz;
+    const float* noise;            // classic mode: the host-drawn stream
     const void* forced;
-    const void* seed;
     void* out;
     float* heads;
     int B, Tf, n_steps, U, N;
+    // extended mode only (in-kernel generator, noise dump, caller's seed waveform)
+    SwnNoise nz;
+    const void* seed;
 };
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }
 constexpr int pow2ceil(int x) { int r = 1; while (r < x) r <<= 1; return r; }
 constexpr int r4(int x) { return (x + 3) & ~3; }
 
-template <int S_, int SEG_, int LPC_, int KIND_, int Q_>
+template <int S_, int SEG_, int LPC_, int KIND_, int Q_, bool EXT_ = false>
 struct Tr {
     static constexpr int S = S_, SEG = SEG_, LPC = LPC_, KIND = KIND_, Q = Q_;
+    static constexpr bool EXT = EXT_;     // extended mode: in-kernel noise generator / noise dump / seed waveform
+    using Ext = Tr<S_, SEG_, LPC_, KIND_, Q_, true>;
     static constexpr int O1 = KIND_ == SWN_KIND_SOFTMAX ? Q_ : S_;
     static constexpr int NO = KIND_ == SWN_KIND_SOFTMAX ? Q_ : 2 * SEG_ + LPC_;
     static constexpr int WN = cmax(1, LPC_) + SEG_;
@@ -69,8 +73,13 @@ struct Tr {
     static constexpr int o_o1 = o_skip + S_;
     static constexpr int o_o2 = o_o1 + O1;
     static constexpr int o_hist = o_o2 + r4(NO);
-    static constexpr int o_tnz = o_hist + r4(WN);         // [2][8] Laplace deviates of the next step
-    static constexpr int o_cz = o_tnz + 16;               // cb[64], cv[2][64], cc[2][64]
+    // sampling noise staged off the critical path: Laplace [4 chunks][64 steps][SEG] transformed deviates (wave 1 fills
+    // a chunk of 64 future steps at once, lane = step); softmax [2 steps][Q] Exp(1) draws (wave 2, one step ahead)
+    static constexpr int NZC = 64, NZB = 4;
+    static constexpr int o_tnz = o_hist + r4(WN);
+    // (the classic Laplace instantiation keeps the round-1 carve: [2][8] deviates of the next step - LDS offsets past
+    //  64 KB cost an address add each, so the layout is part of the measured kernel)
+    static constexpr int o_cz = o_tnz + (KIND_ == SWN_KIND_LAPLACE ? (EXT_ ? r4(NZB * NZC * SEG_) : 16) : 2 * Q_);   // cb[64], cv[2][64], cc[2][64]
     static constexpr int o_w2 = o_cz + 5 * H;             // laplace: out_2 rows [NO][S] (+b2)
     static constexpr int o_bias = o_w2 + (KIND_ == SWN_KIND_LAPLACE ? NO * S_ + r4(NO) : 0);   // bsk[S], b1[O1], (softmax) b2[NO]
     static constexpr int o_wl = o_bias + S_ + O1 + (KIND_ == SWN_KIND_SOFTMAX ? NO : 0);          // [L-NREG][8][512][4]
@@ -320,10 +329,13 @@ __device__ __forceinline__ void tiled_matvec(__amdgpu_buffer_rsrc_t wt, const fl
     }
 }
 
+// EXT = false: the classic instantiation (host-drawn noise stream, zero seed) - the code the round-1 measurements
+// belong to, kept instruction for instruction; EXT = true adds the in-kernel generator / noise dump / seed waveform.
 template <class T>
 __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int SEG = T::SEG, S = T::S, KIND = T::KIND;
+    constexpr bool EXT = T::EXT;
     const int tid = threadIdx.x, b = blockIdx.x;
     const float* __restrict__ P = a.P;
     const int U = a.U;
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
     for (int k = 0; k < WNF; ++k) win[k] = 0.f;
 #pragma unroll
     for (int k = 0; k < WNI; ++k) iwin[k] = T::Q / 2;
-    if (a.seed) {       // seed waveform `audio` of batch_fast_generate: the newest SEG samples / the newest class
+    if (EXT && a.seed) {       // seed waveform `audio` of batch_fast_generate: the newest SEG samples / the newest class
         if constexpr (KIND == SWN_KIND_LAPLACE) {
 #pragma unroll
             for (int j = 0; j < SEG; ++j) win[WNF - SEG + j] = reinterpret_cast<const float*>(a.seed)[(size_t)b * SEG + j];
@@ -464,23 +476,53 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
             }
         }
     };
-    // Laplace deviate of the uniform draw, -> LDS slot of step `step` (computed by wave 1, off the
-    // critical path): tn = sign(e) * log1p(-2|e|)   (cswnv_shift1.py:374-376)
-    // The raw draw is fetched one call earlier still (e_next), so its HBM/L2 latency is never waited on.
+    // Sampling noise, staged in LDS off the critical path (host stream or in-kernel generator: swn_noise.hpp).
+    // Laplace: wave 1 transforms the draws of a whole chunk of 64 future steps at once (lane = step):
+    //   tn = sign(e) * log1p(-2|e|)   (cswnv_shift1.py:374-376); chunk c lives in buffer c & 3 and is filled two chunks
+    //   ahead of its first reader, so the filler needs no barrier of its own.
+    auto noise_chunk = [&](int c) {
+        if (EXT && KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 128) {
+            const int k = tid - 64, step = c * T::NZC + k;
+            if (step < a.n_steps) {
+#pragma unroll
+                for (int j = 0; j < SEG; ++j) {
+                    const float e = swn_noise_laplace(a.nz, b, step, j, a.n_steps, SEG);
+                    const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+                    lds[T::o_tnz + ((c & (T::NZB - 1)) * T::NZC + k) * SEG + j] = sg * log1pf(-2.f * fabsf(e));
+                }
+            }
+        }
+    };
+    // softmax: wave 2 fetches / draws the Q Exp(1) deviates of step `step` (lane t: classes 4t..4t+3) into buffer step & 1
+    auto q_ahead = [&](int step) {
+        if constexpr (KIND == SWN_KIND_SOFTMAX) {
+            static_assert(T::Q == 256, "one float4 of classes per lane");
+            if (tid >= 128 && tid < 192 && step < a.n_steps) {
+                float4 q4;
+                if constexpr (EXT) q4 = swn_noise_exp1x4(a.nz, b, step, tid - 128, a.n_steps, T::Q);
+                else q4 = *reinterpret_cast<const float4*>(a.noise + ((size_t)b * a.n_steps + step) * T::Q + 4 * (tid - 128));
+                *reinterpret_cast<float4*>(lds + T::o_tnz + (step & 1) * T::Q + 4 * (tid - 128)) = q4;
+            }
+        }
+    };
+    // classic mode: wave 1 transforms the deviate of the next step, its raw draw fetched one call earlier still
     float e_next = 0.f;
     auto noise_ahead = [&](int step) {
-        if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG) {
+        if (!EXT && KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG) {
             const int j = tid - 64;
             if (step < a.n_steps) {
                 const float e = e_next;
                 const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
                 lds[T::o_tnz + (step & 1) * 8 + j] = sg * log1pf(-2.f * fabsf(e));
             }
-            if (step + 1 < a.n_steps) e_next = swn_noise_laplace(a.nz, b, step + 1, j, a.n_steps, SEG);
+            if (step + 1 < a.n_steps) e_next = a.noise[((size_t)b * a.n_steps + step + 1) * SEG + j];
         }
     };
-    if (KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG && a.n_steps > 0)
-        e_next = swn_noise_laplace(a.nz, b, 0, tid - 64, a.n_steps, SEG);
+    if (!EXT && KIND == SWN_KIND_LAPLACE && tid >= 64 && tid < 64 + SEG && a.n_steps > 0)
+        e_next = a.noise[(size_t)b * a.n_steps * SEG + (tid - 64)];
+    noise_chunk(0);
+    noise_chunk(1);
+    q_ahead(0);
 
     // ---- prologue: seed positions 0..rf-seg, one position per pass (cswnv_shift1.py:321-334)
 #pragma unroll 1
@@ -511,9 +553,8 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
 #define STAMP(k)
 #endif
     input_gen(RF + 1 - SEG);
-    noise_ahead(0);       // visible to wave 0 after the barriers of step 0
-#pragma unroll 1
-    for (int i = 0; i < a.n_steps; ++i) {
+    noise_ahead(0);       // classic mode: visible to wave 0 after the barriers of step 0
+    auto gen_step = [&](const int i) __attribute__((always_inline)) {
         const int q0 = RF + 1 - SEG + i * SEG;
         float wj[SEG]; int pb[SEG];
 #ifdef SWN_STAMP
@@ -566,9 +607,10 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
             }
         }
         lds_barrier(); STAMP(7)
-        // wave 1 prepares the next step's Laplace deviates while the out_1 weights are in flight; wave 0
-        // left the previous tail long ago, so the slot it overwrites ((i+1)&1 == (i-1)&1) is free
+        // softmax: wave 2 stages the draws of step i+1 (into the buffer wave 0 read in step i-1's tail, which is behind
+        // this step's barriers) while the out_1 weights are in flight
         noise_ahead(i + 1);
+        q_ahead(i + 1);
 #ifndef SWN_W1PREF
         if constexpr (false) {
 #else
@@ -653,7 +695,9 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                         float lpv = 0.f;
 #pragma unroll
                         for (int k = 0; k < T::LPC; ++k) lpv += o2[2 * SEG + T::LPC - 1 - k] * win[T::WN - T::LPC + k];
-                        const float t = bsc * lds[T::o_tnz + (i & 1) * 8 + j];
+                        
+                        const float t = bsc * (EXT ? lds[T::o_tnz + (((i >> 6) & (T::NZB - 1)) * T::NZC + (i & (T::NZC - 1))) * SEG + j]
+                                                   : lds[T::o_tnz + (i & 1) * 8 + j]);
                         float sv = (T::LPC > 0) ? (lpv + mu) - t : mu - t;
                         sv = fminf(fmaxf(sv, -1.f), 1.f);
                         if (tid == 0) outp[j] = sv;
@@ -665,40 +709,36 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
                 }
             }
         } else {
-            // this step's Exp(1) draws of wave 0 are fetched before the out_2 mat-vec: their latency hides under it
             constexpr int Q = T::Q;
             constexpr int QL = Q > 0 ? (Q + 63) / 64 : 1;     // classes per lane (this branch is also compiled for Laplace nets)
-            float qv[QL];
-            if (tid < 64) {
-#pragma unroll
-                for (int k = 0; k < QL; ++k) qv[k] = tid + 64 * k < Q ? swn_noise_exp1(a.nz, b, i, tid + 64 * k, a.n_steps, Q) : 1.f;
-            }
             tiled_matvec<T::NO, T::O1>(w22, lds + T::o_bias + S + T::O1, lds + T::o_o1, lds + T::o_o2, false);
             lds_barrier();
             if (HEADS_ON && a.heads)
                 for (int e = tid; e < T::NO; e += NT) a.heads[((size_t)b * a.n_steps + i) * T::NO + e] = lds[T::o_o2 + e];
             if (tid < 64) {
                 // softmax head, dswnv.py:361-369: p = softmax(logits); p /= sum(p); index = argmax(p / q).
-                // exp(logit - max) is evaluated once per class and kept in registers for the three passes.
-                const float* o2v = lds + T::o_o2;
-                float lg[QL], ex[QL];
-                float m = -INFINITY;
-#pragma unroll
-                for (int k = 0; k < QL; ++k) { lg[k] = tid + 64 * k < Q ? o2v[tid + 64 * k] : -INFINITY; m = fmaxf(m, lg[k]); }
+                // lane t owns classes 4t..4t+3 (one 16-byte LDS read each for logits and noise); exp(logit - max) is
+                // evaluated once per class and kept in registers for the three passes.
+                static_assert(KIND != SWN_KIND_SOFTMAX || QL == 4, "four classes per lane");
+                const float4 l4 = *reinterpret_cast<const float4*>(lds + T::o_o2 + 4 * tid);
+                const float4 q4 = *reinterpret_cast<const float4*>(lds + T::o_tnz + (i & 1) * Q + 4 * tid);
+                const float lg[4] = {l4.x, l4.y, l4.z, l4.w}, qv[4] = {q4.x, q4.y, q4.z, q4.w};
+                float ex[4];
+                float m = fmaxf(fmaxf(lg[0], lg[1]), fmaxf(lg[2], lg[3]));
                 for (int d = 32; d >= 1; d >>= 1) m = fmaxf(m, __shfl_xor(m, d, 64));
                 float sum = 0.f;
 #pragma unroll
-                for (int k = 0; k < QL; ++k) { ex[k] = tid + 64 * k < Q ? expf(lg[k] - m) : 0.f; sum += ex[k]; }
+                for (int k = 0; k < 4; ++k) { ex[k] = expf(lg[k] - m); sum += ex[k]; }
                 for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
                 float sum2 = 0.f;
 #pragma unroll
-                for (int k = 0; k < QL; ++k) { ex[k] = ex[k] / sum; sum2 += ex[k]; }
+                for (int k = 0; k < 4; ++k) { ex[k] = ex[k] / sum; sum2 += ex[k]; }
                 for (int d = 32; d >= 1; d >>= 1) sum2 += __shfl_xor(sum2, d, 64);
                 float best = -1.f; int bi = 0x7fffffff;
 #pragma unroll
-                for (int k = 0; k < QL; ++k) {
+                for (int k = 0; k < 4; ++k) {
                     const float r = (ex[k] / sum2) / qv[k];
-                    if (tid + 64 * k < Q && r > best) { best = r; bi = tid + 64 * k; }
+                    if (r > best) { best = r; bi = 4 * tid + k; }
                 }
                 for (int d = 32; d >= 1; d >>= 1) {
                     const float ob = __shfl_xor(best, d, 64);
@@ -715,6 +755,20 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
         // next step's input layer, still inside wave 0 (no barrier between sampling and h0)
         if (i + 1 < a.n_steps) input_gen(q0 + SEG);
         STAMP(9)
+    };
+    if constexpr (EXT) {
+        // chunks of 64 steps: wave 1 fills the noise of chunk c+2 at the top of chunk c (buffer (c+2)&3 held chunk c-2,
+        // whose readers are two chunks behind)
+#pragma unroll 1
+        for (int i0 = 0; i0 < a.n_steps; i0 += T::NZC) {
+            noise_chunk((i0 >> 6) + 2);
+            const int iend = i0 + T::NZC < a.n_steps ? i0 + T::NZC : a.n_steps;
+#pragma unroll 1
+            for (int i = i0; i < iend; ++i) gen_step(i);
+        }
+    } else {
+#pragma unroll 1
+        for (int i = 0; i < a.n_steps; ++i) gen_step(i);
     }
 #ifdef SWN_STAMP
     if (tid == 0 && b == 0 && a.heads)
@@ -723,7 +777,7 @@ __global__ __launch_bounds__(NT) void decode_bl6_kernel(const B6Args a) {
 }
 
 template <class T>
-int launch(const B6Args& a, hipStream_t st) {
+int launch_mode(const B6Args& a, hipStream_t st) {
     static_assert(T::lds_bytes <= 160 * 1024, "LDS budget");
     auto kern = decode_bl6_kernel<T>;
     if (T::lds_bytes > 64 * 1024) {
@@ -733,6 +787,12 @@ int launch(const B6Args& a, hipStream_t st) {
     }
     hipLaunchKernelGGL(kern, dim3(a.B), dim3(NT), T::lds_bytes, st, a);
     return swn_launch_status("swn_decode(bl6)");
+}
+
+template <class T>
+int launch(const B6Args& a, hipStream_t st) {
+    const bool ext = !a.nz.ptr || a.nz.dump || a.seed;
+    return ext ? launch_mode<typename T::Ext>(a, st) : launch_mode<T>(a, st);
 }
 
 }  // namespace
@@ -745,7 +805,7 @@ extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, co
     if (!g.bl6 || g.U > 256 || g.U < 2 * g.seg || g.audio_in) return SWN_E_UNSUPPORTED;
     B6Args a;
     swn_make_layout(&g, &a.y);
-    a.P = packed; a.cond = cond; a.nz = *nz; a.forced = forced; a.seed = seed; a.out = out; a.heads = heads;
+    a.P = packed; a.cond = cond; a.noise = nz->ptr; a.nz = *nz; a.forced = forced; a.seed = seed; a.out = out; a.heads = heads;
     a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.U = g.U; a.N = g.N;
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported

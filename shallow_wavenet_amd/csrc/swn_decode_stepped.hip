@@ -333,9 +333,22 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
         for (int e = tid; e < Q; e += 64) sum2 += expf(o2v[e] - m) / sum;
         for (int d = 32; d >= 1; d >>= 1) sum2 += __shfl_xor(sum2, d, 64);
         float best = -1.f; int bi = 0x7fffffff;
-        for (int e = tid; e < Q; e += 64) {
-            const float r = ((expf(o2v[e] - m) / sum) / sum2) / swn_noise_exp1(a.nz, b, i, e, a.n_steps, Q);
-            if (r > best) { best = r; bi = e; }
+        if ((Q & 3) == 0) {          // four classes per generator call / 16-byte noise load
+            for (int g4 = tid; 4 * g4 < Q; g4 += 64) {
+                const float4 q4 = swn_noise_exp1x4(a.nz, b, i, g4, a.n_steps, Q);
+                const float qv[4] = {q4.x, q4.y, q4.z, q4.w};
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int e = 4 * g4 + k;
+                    const float r = ((expf(o2v[e] - m) / sum) / sum2) / qv[k];
+                    if (r > best) { best = r; bi = e; }
+                }
+            }
+        } else {
+            for (int e = tid; e < Q; e += 64) {
+                const float r = ((expf(o2v[e] - m) / sum) / sum2) / swn_noise_exp1(a.nz, b, i, e, a.n_steps, Q);
+                if (r > best) { best = r; bi = e; }
+            }
         }
         for (int d = 32; d >= 1; d >>= 1) {
             const float ob = __shfl_xor(best, d, 64);

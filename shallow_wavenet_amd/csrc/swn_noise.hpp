@@ -64,3 +64,22 @@ __device__ __forceinline__ float swn_noise_exp1(const SwnNoise& n, int b, int st
     if (n.dump) n.dump[at] = q;
     return q;
 }
+
+// the four Exp(1) draws of classes 4g .. 4g+3 (one generator call): same values as swn_noise_exp1 element by element.
+// Q must be a multiple of 4.
+__device__ __forceinline__ float4 swn_noise_exp1x4(const SwnNoise& n, int b, int step, int g, int n_steps, int Q) {
+    const size_t at = ((size_t)b * n_steps + step) * Q + 4 * (size_t)g;
+    float4 q;
+    if (n.ptr) {
+        q = *reinterpret_cast<const float4*>(n.ptr + at);
+    } else {
+        const uint4 r = swn_philox4x32_10(make_uint4(n.utt0 + (uint32_t)b, (uint32_t)step, (uint32_t)g, 0x45585031u),
+                                          make_uint2(n.key0, n.key1));
+        q.x = -logf(((float)(r.x >> 9) + 0.5f) * 1.1920928955078125e-7f);
+        q.y = -logf(((float)(r.y >> 9) + 0.5f) * 1.1920928955078125e-7f);
+        q.z = -logf(((float)(r.z >> 9) + 0.5f) * 1.1920928955078125e-7f);
+        q.w = -logf(((float)(r.w >> 9) + 0.5f) * 1.1920928955078125e-7f);
+    }
+    if (n.dump) *reinterpret_cast<float4*>(n.dump + at) = q;
+    return q;
+}
