@@ -30,7 +30,7 @@ from typing import Iterator, List, Sequence, Tuple
 import numpy as np
 import torch
 
-from . import artefacts, dist as D
+from . import artefacts, dist as D, featio
 from .nets import cswnv_shift1 as laplace_mod
 from .nets import dswnv as softmax_mod
 from .runtime import HipNet, pack_state_dict
@@ -38,29 +38,19 @@ from .runtime import HipNet, pack_state_dict
 
 # --------------------------------------------------------------------------- feature / list I/O
 def read_feature(path: str, string_path: str = "/feat_org_lf0") -> np.ndarray:
-    if path.endswith(".npy"):
-        return np.load(path, allow_pickle=False)
-    if path.endswith(".h5"):
-        try:
-            import h5py  # noqa: WPS433  (optional dependency, absent in the build image)
-        except ImportError as e:
-            raise RuntimeError("reading .h5 features needs h5py; convert to .npy or install h5py") from e
-        with h5py.File(path, "r") as f:
-            return f[string_path][()]
-    raise RuntimeError(f"unsupported feature file {path}")
+    """(Tf, n_aux) features of one utterance: HDF5 / .npz dataset `string_path` or a plain .npy (featio.py)."""
+    return featio.read_dataset(featio.resolve(path), string_path)
 
 
 def feature_frames(path: str, string_path: str) -> int:
-    if path.endswith(".npy"):
-        return int(np.load(path, mmap_mode="r", allow_pickle=False).shape[0])
-    return int(read_feature(path, string_path).shape[0])
+    return int(featio.dataset_shape(featio.resolve(path), string_path)[0])
 
 
 def list_features(feats: str) -> List[str]:
     """directory -> sorted recursive *.h5 / *.npy ; file -> one path per line (utils.py:129-160)."""
     if os.path.isdir(feats):
         out = []
-        for ext in ("*.h5", "*.npy"):
+        for ext in ("*.h5", "*.npz", "*.npy"):
             out += glob.glob(os.path.join(feats, "**", ext), recursive=True)
         return sorted(out)
     if os.path.isfile(feats):

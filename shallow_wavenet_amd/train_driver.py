@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from . import artefacts
+from . import artefacts, featio
 
 FFT_FACTS = {5: [128, 256, 512, 1024, 2048],
              9: [128, 192, 256, 384, 512, 768, 1024, 1536, 2048],
@@ -112,28 +112,13 @@ def read_wav(path: str) -> np.ndarray:
 
 
 def read_feat(path: str, string_path: str) -> np.ndarray:
-    """(Tf, n_aux) features: HDF5 dataset `string_path` (utils.py read_hdf5) or `<stem>.npy`."""
-    try:
-        import h5py
-        with h5py.File(path, "r") as f:
-            return np.asarray(f[string_path][()])
-    except ImportError:
-        return np.load(os.path.splitext(path)[0] + ".npy", allow_pickle=False)
+    """(Tf, n_aux) features: HDF5 dataset `string_path` (utils.py read_hdf5) or its .npz / .npy side file (featio.py)."""
+    return np.asarray(featio.read_dataset(featio.resolve(path), string_path))
 
 
 def read_stats(path: str, string_path: str) -> Tuple[np.ndarray, np.ndarray]:
     """mean / scale of the features -> scale_in initialisation (train_cswnv...py:316-345)."""
-    name = string_path.split("feat_")[1]
-    try:
-        import h5py
-        with h5py.File(path, "r") as f:
-            for pre in ("/mean_" + name, "/mean_" + string_path, "/mean_feat_" + name):
-                if pre in f:
-                    return np.asarray(f[pre][()]), np.asarray(f[pre.replace("mean", "scale", 1)][()])
-        raise KeyError(path)
-    except ImportError:
-        z = np.load(os.path.splitext(path)[0] + ".npz", allow_pickle=False)
-        return z["mean"], z["scale"]
+    return featio.read_stats(path, string_path)
 
 
 def train_generator(wav_list: Sequence, feat_list: Sequence, receptive_field: int, string_path: str = "/feat_org_lf0",
