@@ -96,14 +96,46 @@ SIGNATURES = {
 }
 
 
+STAMP_PATH = os.path.join(_HERE, "libswn_hip.so.srchash")
+
+
+def source_hash() -> str:
+    """sha256 over everything the library is built from: csrc/* sources + Makefile + the public header."""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cpp", ".hpp")) or f == "Makefile")
+    for path in [os.path.join(CSRC, f) for f in files] + [os.path.join(os.path.dirname(_HERE), "include", "swn_hip.h")]:
+        h.update(os.path.basename(path).encode() + b"\0")
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
+def is_stale() -> bool:
+    """True when the in-tree .so is missing or was not built from the sources now in the tree (the .so and its
+    hash stamp are git-ignored but travel to the GPU box, so a stale binary would otherwise go unnoticed)."""
+    if not (os.path.exists(LIB_PATH) and os.path.exists(STAMP_PATH)):
+        return True
+    with open(STAMP_PATH) as f:
+        return f.read().strip() != source_hash()
+
+
 def build(force: bool = False) -> str:
-    """compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU)."""
-    if force:
+    """compile the HIP library in-tree (hipcc cross-compiles gfx950 without a GPU).  A library whose recorded source
+    hash differs from the tree is rebuilt from scratch; `force` rebuilds regardless."""
+    if force or is_stale():
         subprocess.run(["make", "-C", CSRC, "clean"], check=True, capture_output=True)
-    r = subprocess.run(["make", "-C", CSRC, "-j4"], capture_output=True, text=True)
+    r = subprocess.run(["make", "-C", CSRC, "-j8"], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError("building libswn_hip.so failed:\n" + r.stdout + r.stderr)
+    write_stamp()
     return LIB_PATH
+
+
+def write_stamp() -> None:
+    """record which sources the in-tree .so was built from (also called by csrc/Makefile after linking)."""
+    with open(STAMP_PATH, "w") as f:
+        f.write(source_hash() + "\n")
 
 
 def lib() -> ctypes.CDLL:

@@ -12,7 +12,10 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import ops as _ops          # registers torch.ops.swn.*
 from .config import NetConfig
+
+_O = torch.ops.swn
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -127,6 +130,7 @@ class HipNet:
             raise RuntimeError("shallow_wavenet_amd needs a HIP device (no CPU fallback)")
         self.cfg = cfg
         self.desc = _lib.desc_from_cfg(cfg)
+        self.dlist = _ops.desc_list(cfg)          # the same descriptor as the integer list the custom ops take
         self.device = torch.device(device)
         self.lib = _lib.lib()
         self.packed = packed.to(self.device, non_blocking=False).contiguous()
@@ -144,20 +148,10 @@ class HipNet:
 
     # ------------------------------------------------------------------ front end
     def frontend(self, aux: torch.Tensor) -> torch.Tensor:
-        """aux (B, n_aux, Tf) fp32 on device -> cond (B, Tf, L*seg*2H)."""
-        cfg, L = self.cfg, self.lib
-        aux = aux.to(self.device, torch.float32).contiguous()
-        B, na, Tf = aux.shape
-        if na != cfg.n_aux:
-            raise RuntimeError(f"aux has {na} channels, model expects {cfg.n_aux}")
-        d = ctypes.byref(self.desc)
-        work = torch.empty(L.swn_frontend_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-        cond = torch.empty(L.swn_cond_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(L.swn_frontend(d, _ptr(self.packed), _ptr(aux), B, Tf, _ptr(work), _ptr(cond),
-                                      _stream_ptr(self.device)), "frontend")
+        """aux (B, n_aux, Tf) fp32 on device -> cond (B, Tf, L*seg*2H)   (torch.ops.swn.frontend)."""
+        cond, work = _O.frontend(self.packed, aux.to(self.device), self.dlist)
         self._last_frontend_work = work            # kept for swn_backward (conv_aux activations)
-        return cond.view(B, Tf, -1)
+        return cond
 
     # ------------------------------------------------------------------ decode
     def decode(self, aux: torch.Tensor, n_steps: int, noise: Optional[torch.Tensor] = None,
@@ -174,36 +168,12 @@ class HipNet:
         returns (out, heads): out laplace (B, n_steps*seg) fp32 | softmax (B, n_steps) int32; with want_noise=True
         a third value: the noise the kernels used, in the layout of `noise`.
         """
-        cfg, L = self.cfg, self.lib
-        soft = cfg.kind == "softmax"
         if cond is None:
             cond = self.frontend(aux)
-        B, Tf = cond.shape[0], cond.shape[1]
-        seg = 1 if soft else cfg.seg
-        width = cfg.n_quantize if soft else seg
-        if noise is not None:
-            noise = noise.to(self.device, torch.float32).contiguous()
-            if tuple(noise.shape) != (B, n_steps, width):
-                raise RuntimeError(f"noise shape {tuple(noise.shape)} != {(B, n_steps, width)}")
-        if forced is not None:
-            forced = forced.to(self.device, torch.int32 if soft else torch.float32).contiguous()
-            if forced.numel() != B * n_steps * seg:
-                raise RuntimeError("forced history has the wrong size")
-        if seed is not None:
-            seed = seed.to(self.device, torch.int32 if soft else torch.float32).contiguous()
-            if seed.numel() != B * seg:
-                raise RuntimeError(f"seed waveform has {seed.numel()} elements, expected {B * seg}")
-        d = ctypes.byref(self.desc)
-        state = torch.empty(L.swn_decode_state_floats(d, B), dtype=torch.float32, device=self.device)
-        out = torch.empty((B, n_steps * seg), dtype=torch.int32 if soft else torch.float32, device=self.device)
-        heads = torch.empty((B, n_steps, cfg.n_out), dtype=torch.float32, device=self.device) if want_heads else None
-        used = torch.empty((B, n_steps, width), dtype=torch.float32, device=self.device) if want_noise else None
-        io = _lib.DecodeIO(noise_dev=_ptr(noise), forced_dev=_ptr(forced), seed_dev=_ptr(seed), noise_out_dev=_ptr(used),
-                           rng_seed=int(rng_seed) & 0xFFFFFFFFFFFFFFFF, rng_utt0=int(rng_utt0) & 0xFFFFFFFF, reserved=0)
-        with torch.cuda.device(self.device):
-            _lib.check(L.swn_decode(d, _ptr(self.packed), _ptr(cond), B, Tf, n_steps, ctypes.byref(io),
-                                    _ptr(state), _ptr(out), _ptr(heads), variant,
-                                    _stream_ptr(self.device)), "decode")
+        out, heads, used = _O.decode(self.packed, cond, noise, forced, seed, self.dlist, int(n_steps), int(variant),
+                                     int(rng_seed) & 0x7FFFFFFFFFFFFFFF, int(rng_utt0) & 0xFFFFFFFF, bool(want_heads),
+                                     bool(want_noise))
+        heads = heads if want_heads else None
         if want_noise:
             return out, heads, used
         return out, heads
@@ -211,72 +181,27 @@ class HipNet:
     # ------------------------------------------------------------------ teacher-forced stack
     def forward(self, aux: torch.Tensor, audio: torch.Tensor, want_hidden: bool = False,
                 cond: Optional[torch.Tensor] = None):
-        """raw out_2 outputs (B, n_out, Tp) of the teacher-forced stack.
+        """raw out_2 outputs (B, n_out, Tp) of the teacher-forced stack (torch.ops.swn.stack_forward).
         audio: laplace (B, 1, T-seg) fp32 | softmax (B, T-1) integer indices."""
-        cfg, L = self.cfg, self.lib
-        soft = cfg.kind == "softmax"
         if cond is None:
             cond = self.frontend(aux)
-        B, Tf = cond.shape[0], cond.shape[1]
-        T = Tf * cfg.U
-        seg = 1 if soft else cfg.seg
-        Tp = T - 1 if soft else T - 2 * seg + 1
-        audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
-        need = B * (T - seg)
-        if audio.numel() != need:
-            raise RuntimeError(f"audio has {audio.numel()} elements, expected {need}")
-        d = ctypes.byref(self.desc)
-        work = torch.empty(L.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
-        hs = torch.empty((B, cfg.L + 1, cfg.H, Tp), dtype=torch.float32, device=self.device) if want_hidden else None
-        with torch.cuda.device(self.device):
-            _lib.check(L.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
-                                     _ptr(out), _ptr(hs), _stream_ptr(self.device)), "forward")
-        return out, hs
+        out, _work, hs = _O.stack_forward(self.packed, cond, audio.to(self.device), self.dlist, bool(want_hidden))
+        return out, (hs if want_hidden else None)
 
     def forward_bf16(self, aux: torch.Tensor, audio: torch.Tensor, cond: Optional[torch.Tensor] = None):
         """bf16 MFMA variant of `forward` (BL6-class Laplace nets and H%64==0 nets of either kind): raw (B, n_out, Tp) fp32."""
-        cfg, L = self.cfg, self.lib
-        d = ctypes.byref(self.desc)
-        nbytes = L.swn_bf16_weight_bytes(d)
-        if nbytes == 0:
-            raise RuntimeError("bf16 stack kernels are built for the BL6-class and the H%64==0 Laplace geometries only")
         if cond is None:
             cond = self.frontend(aux)
-        B, Tf = cond.shape[0], cond.shape[1]
         if getattr(self, "_wbf16", None) is None or getattr(self, "_wbf16_version", -1) != self.packed_version:
-            if getattr(self, "_wbf16", None) is None:
-                self._wbf16 = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
-            with torch.cuda.device(self.device):
-                _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _stream_ptr(self.device)), "pack_bf16")
+            self._wbf16 = _O.pack_bf16(self.packed, self.dlist)
             self._wbf16_version = self.packed_version
-        soft = cfg.kind == "softmax"
-        Tp = Tf * cfg.U - 1 if soft else Tf * cfg.U - 2 * cfg.seg + 1
-        audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
-        if audio.numel() != B * (Tp if soft else Tf * cfg.U - cfg.seg):
-            raise RuntimeError("audio has the wrong size")
-        work = torch.empty(L.swn_forward_bf16_work_bytes(d, B, Tf), dtype=torch.uint8, device=self.device)
-        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
-                                          _ptr(work), _ptr(out), _stream_ptr(self.device)), "forward_bf16")
+        out, _work = _O.stack_forward_bf16(self.packed, self._wbf16, cond, audio.to(self.device), self.dlist)
         return out
 
     def laplace_head(self, raw: torch.Tensor, clip: bool = False):
-        """raw (B, n_out, Tp) -> (mu, b, logb, a, b_clip, logb_clip, below_floor) time-major."""
-        cfg, L = self.cfg, self.lib
-        B, NO, Tp = raw.shape
-        seg, lpc = cfg.seg, cfg.lpc
-        mk = lambda w: torch.empty((B, Tp, w), dtype=torch.float32, device=self.device)
-        mu, b, logb = mk(seg), mk(seg), mk(seg)
-        a = mk(lpc) if lpc > 0 else None
-        bc, lc = (mk(seg), mk(seg)) if clip else (None, None)
-        flag = torch.zeros(1, dtype=torch.int32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(L.swn_laplace_head(ctypes.byref(self.desc), _ptr(raw.contiguous()), B, Tp, _ptr(mu), _ptr(b),
-                                          _ptr(logb), _ptr(a), _ptr(bc), _ptr(lc), _ptr(flag),
-                                          _stream_ptr(self.device)), "laplace_head")
-        return mu, b, logb, a, bc, lc, flag
+        """raw (B, n_out, Tp) -> (mu, b, logb, a, b_clip, logb_clip, below_floor) time-major (torch.ops.swn.laplace_head)."""
+        mu, b, logb, a, bc, lc, flag = _O.laplace_head(raw, self.dlist, bool(clip))
+        return mu, b, logb, (a if self.cfg.lpc > 0 else None), (bc if clip else None), (lc if clip else None), flag
 
 
     # ------------------------------------------------------------------ training (fp32)
@@ -294,15 +219,13 @@ class HipNet:
         T = Tf * cfg.U
         Tp = T - 1 if soft else T - 2 * cfg.seg + 1
         audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
-        d = ctypes.byref(self.desc)
-        work = torch.empty(self.lib.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-        out = self._bf16_train_forward(cond, audio, B, Tf, work) if self.lib.swn_train_get_precision() == 1 else None
-        if out is not None:
-            return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
-        out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.swn_forward(d, _ptr(self.packed), _ptr(cond), _ptr(audio), B, Tf, _ptr(work),
-                                            _ptr(out), _ptr(None), _stream_ptr(self.device)), "forward")
+        if self.lib.swn_train_get_precision() == 1:
+            d = ctypes.byref(self.desc)
+            work = torch.empty(self.lib.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+            out = self._bf16_train_forward(cond, audio, B, Tf, work)
+            if out is not None:
+                return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
+        out, work, _ = _O.stack_forward(self.packed, cond, audio, self.dlist, False)
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
 
     def _bf16_train_forward(self, cond, audio, B, Tf, work):
@@ -379,21 +302,8 @@ class HipNet:
                                                ctypes.cast(ptrs, ctypes.c_void_p), _ptr(grad_raw), B, Tf, _ptr(work),
                                                _ptr(gp), _stream_ptr(self.device)), "backward_drop")
             return gp
-        work = torch.empty(L.swn_backward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-        gp = torch.empty_like(self.packed)
-        with torch.cuda.device(self.device):
-            _lib.check(L.swn_backward(d, _ptr(self.packed), _ptr(saved["aux"]), _ptr(saved["cond"]), _ptr(saved["fe_work"]),
-                                      _ptr(saved["audio"]), _ptr(saved["work"]), _ptr(None), _ptr(grad_raw), B, Tf,
-                                      _ptr(work), _ptr(gp), _stream_ptr(self.device)), "backward")
-        return gp
+        return _O.stack_backward(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
+                                 saved["work"], grad_raw, self.dlist)
 
     def laplace_head_backward(self, raw, gmu, gb, glogb, ga, gb_clip=None, glogb_clip=None) -> torch.Tensor:
-        B, NO, Tp = raw.shape
-        c = lambda t: None if t is None else t.to(self.device, torch.float32).contiguous()
-        gmu, gb, glogb, ga, gb_clip, glogb_clip = c(gmu), c(gb), c(glogb), c(ga), c(gb_clip), c(glogb_clip)
-        graw = torch.empty_like(raw)
-        with torch.cuda.device(self.device):
-            _lib.check(self.lib.swn_laplace_head_backward(ctypes.byref(self.desc), _ptr(raw), B, Tp, _ptr(gmu), _ptr(gb),
-                                                          _ptr(glogb), _ptr(ga), _ptr(gb_clip), _ptr(glogb_clip),
-                                                          _ptr(graw), _stream_ptr(self.device)), "laplace_head_backward")
-        return graw
+        return _O.laplace_head_backward(raw, gmu, gb, glogb, ga, gb_clip, glogb_clip, self.dlist)

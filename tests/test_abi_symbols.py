@@ -117,3 +117,14 @@ def test_pack_layout_known_answers():
     o_wd = o
     Hp = (H + 3) & ~3
     assert packed[o_wd + ((4 * 2 * H + 33) * K + 2) * Hp + 11] == sd["dil_h.4.conv.weight"][33, 11, 2]
+
+
+def test_in_tree_library_was_built_from_the_sources_in_the_tree():
+    """build() rebuilds when the recorded source hash (csrc/*, Makefile, include/swn_hip.h) differs from the tree:
+    a stale .so cannot pass silently."""
+    from shallow_wavenet_amd import _lib
+    _lib.lib()
+    assert os.path.exists(_lib.STAMP_PATH), "library without a source-hash stamp: run __graft_entry__.build()"
+    assert not _lib.is_stale(), "libswn_hip.so does not match csrc/: run __graft_entry__.build()"
+    h = _lib.source_hash()
+    assert len(h) == 64 and h == _lib.source_hash()
