@@ -166,7 +166,7 @@ def _module(cfg, sd, dev):
 
 
 def decode_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, fs: int, reps: int, kernel: str, variant: int = 0,
-               caller: bool = False):
+               caller: bool = False, steady: bool = False):
     """one decode workload: kernel time by HIP events (inputs resident), samples/s, real-time factor per utterance,
     HBM roofline on SURVEY 8(d)'s algorithmic bytes; optionally `batch_fast_generate` as the caller sees it."""
     soft = cfg.kind == "softmax"
@@ -192,6 +192,14 @@ def decode_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, fs: int, reps:
            "host_noise_draw_s": round(host_noise_s, 4),
            "roofline": _hbm(bpp * positions, ms, kernel=kernel, algorithmic_bytes_per_position=round(bpp, 1),
                             positions_per_launch=positions)}
+    if steady:
+        # short utterance: the rf-position prologue weighs on the figure above; the per-step cost of a long utterance is
+        # the slope between this decode and one of half the length (same launch chain, same prologue)
+        half = n_steps // 2
+        ms_half = _hip_timed(lambda: net.decode(aux, half, noise[:, :half].contiguous(), cond=cond, variant=variant), reps, warm=1)
+        us = (ms - ms_half) * 1e3 / (n_steps - half)
+        leg["steady_state_us_per_step"] = round(us, 3)
+        leg["steady_state_real_time_factor"] = round(seg / (us * 1e-6) / fs, 2)
     if caller:
         m = _module(cfg, sd, dev)
         m.set_packed_engine(net)
@@ -314,15 +322,15 @@ def run_legs(dev, quick: bool = False):
         bl6, dev, 64, 600, 22050, 2, "decode_bl6_kernel")
     # run.sh geometry (REF6: 3x2 layers, K=7, H=192/256): companions of cfg1/2/3/5, 440-step decodes (+690-position prologue)
     r_tf = 4
-    stepped = "stepped decode: step_layer_kernel x L + rowvec_kernel x 2 + step_tail_kernel per step"
+    stepped = "stepped decode: step_layer_kernel x L + rowvec_kernel x 2 (3 for the softmax head) + step_tail_kernel per step"
     add("ref6_cfg2", decode_leg, "REF6 companion of cfg2: CSWNV run.sh geometry (H=192, S=256, K=7, 3x2) seg=1 lpc=4, 1 utterance x Tf=4",
-        C.ref6_laplace(1, 4), dev, 1, r_tf, 22050, 2, stepped)
+        C.ref6_laplace(1, 4), dev, 1, r_tf, 22050, 2, stepped, steady=True)
     add("ref6_cfg3", decode_leg, "REF6 companion of cfg3: seg=5 lpc=4, 1 utterance x Tf=4",
-        C.ref6_laplace(5, 4), dev, 1, r_tf, 22050, 2, stepped)
+        C.ref6_laplace(5, 4), dev, 1, r_tf, 22050, 2, stepped, steady=True)
     add("ref6_cfg1", decode_leg, "REF6 companion of cfg1: DSWNV run.sh geometry (H=256, K=7, 3x2, Q=256), 22.05 kHz, 1 utterance x Tf=4",
-        C.ref6_softmax(), dev, 1, r_tf, 22050, 2, stepped)
+        C.ref6_softmax(), dev, 1, r_tf, 22050, 2, stepped, steady=True)
     add("ref6_cfg5_share", decode_leg, "REF6 companion of cfg5's share: 64 utterances x Tf=4, seg=1 lpc=4",
-        C.ref6_laplace(1, 4), dev, 64, r_tf, 22050, 1, stepped)
+        C.ref6_laplace(1, 4), dev, 64, r_tf, 22050, 1, stepped, steady=True)
     if quick:
         return legs
     # cfg4: teacher-forced stack, 8 x 16 500 (BASELINE's size) and 64 x 16 500

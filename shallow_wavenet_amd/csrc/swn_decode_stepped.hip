@@ -28,6 +28,7 @@ struct StArgs {
     int B, Tf, n_steps, n_pro, WN;
     int ring_off[SWN_MAXL], ring_len[SWN_MAXL];
     int o_hcat, o_skip, o_o1, o_o2, o_hist, o_cnt, stride;      // per-utterance float offsets
+    int o2_by_rowvec;                                           // out_2 was computed by a rowvec launch into o_o2 (wide heads)
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -261,8 +262,12 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
     float* st = a.state + (size_t)b * a.stride;
     const int i = it - a.n_pro, seg = g.seg, WN = a.WN;
-    // out_2 rows: 8 rows per pass, 32 lanes per row; branch-free loads (a row past NO / an input past O1p reads zeros)
-    {
+    // out_2.  Wide heads (softmax: Q rows) arrive from a rowvec launch - one wave per row over the chip, like skip and
+    // out_1 - in the state block; narrow heads (Laplace: <= 2 seg + lpc rows) are computed here:
+    // 8 rows per pass, 32 lanes per row; branch-free loads (a row past NO / an input past O1p reads zeros)
+    if (a.o2_by_rowvec) {
+        for (int e = tid; e < g.NO; e += 256) o2v[e] = st[a.o_o2 + e];
+    } else {
         const __amdgpu_buffer_rsrc_t rP = st_rsrc(a.P), rS = st_rsrc(a.state);
         const size_t xb = (size_t)b * a.stride + a.o_o1;
         for (int r0 = 0; r0 < g.NO; r0 += 8) {
@@ -420,6 +425,8 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     plan(a);
     a.P = packed; a.cond = cond; a.nz = *nz; a.forced = forced; a.seed = seed; a.state = state; a.out = out; a.heads = heads;
     a.B = batch; a.Tf = n_frames; a.n_steps = n_steps; a.n_pro = g.rf - g.seg + 1;
+    // one 256-thread workgroup evaluates 8 rows per pass: beyond 64 rows (8 passes, ~7 us) a launch of its own is cheaper
+    a.o2_by_rowvec = g.NO > 64 ? 1 : 0;
     hipStream_t st = (hipStream_t)stream_;
     if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.stride * batch, st) != hipSuccess) return SWN_E_LAUNCH;
     if (g.kind == SWN_KIND_SOFTMAX || seed) hipLaunchKernelGGL(step_seed_kernel, dim3(batch), dim3(64), 0, st, a);
@@ -448,9 +455,9 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
         }
     };
 #undef SWN_LAYER
-    auto rowvec = [&](int rows, size_t w_off, int ldw, size_t b_off, int nin, int x_off, int y_off) {
-        if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, 1);
-        else hipLaunchKernelGGL(rowvec_kernel<8>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, 1);
+    auto rowvec = [&](int rows, size_t w_off, int ldw, size_t b_off, int nin, int x_off, int y_off, int relu) {
+        if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
+        else hipLaunchKernelGGL(rowvec_kernel<8>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
     };
     const int total = a.n_pro + n_steps;
     for (int it = 0; it < total; ++it) {
@@ -462,8 +469,9 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
         }
         layers(it);
         if (it < a.n_pro) continue;
-        rowvec(g.S, a.y.wsk, g.L * g.Hp, a.y.bsk, g.L * g.Hp, a.o_hcat, a.o_skip);
-        rowvec(g.O1, a.y.w1, g.Sp, a.y.b1, g.Sp, a.o_skip, a.o_o1);
+        rowvec(g.S, a.y.wsk, g.L * g.Hp, a.y.bsk, g.L * g.Hp, a.o_hcat, a.o_skip, 1);
+        rowvec(g.O1, a.y.w1, g.Sp, a.y.b1, g.Sp, a.o_skip, a.o_o1, 1);
+        if (a.o2_by_rowvec) rowvec(g.NO, a.y.w2, g.O1p, a.y.b2, g.O1p, a.o_o1, a.o_o2, 0);
         if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(256), 0, st, a, it);
         else hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_SOFTMAX>, dim3(batch), dim3(256), 0, st, a, it);
     }
