@@ -125,8 +125,24 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
                 const float* c2b = a.t[a.i_c2d + 1];
                 for (int p = 0; p < g.A0; ++p) bo += (double)w[(size_t)o * g.A0 + p] * c2b[p];
             }
-            for (int c = 0; c < g.A0; ++c)
-                for (int s = 0; s < seg; ++s) ws += inx_eff(a, l, o, c, s);
+            if (!g.conv2d) {
+                // same c-major, s-minor order as the host packer; the loads of 16 terms are issued together (the
+                // loop is otherwise one dependent L2 round trip per term: 486 of them per thread)
+                const int A = g.A0 * seg + (g.audio_in ? Q : 0), n = g.A0 * seg;
+                const float* row = a.t[a.i_inx + 2 * l] + (size_t)o * A;
+                int k = 0;
+                for (; k + 16 <= n; k += 16) {
+                    float v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v[u] = row[k + u];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) ws += v[u];
+                }
+                for (; k < n; ++k) ws += row[k];
+            } else {
+                for (int c = 0; c < g.A0; ++c)
+                    for (int s = 0; s < seg; ++s) ws += inx_eff(a, l, o, c, s);
+            }
             out[y.bx + e] = (float)(bo + (double)bup * ws);
             out[y.bxr + e] = (float)bo;
         }
