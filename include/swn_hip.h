@@ -117,7 +117,11 @@ int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float*
  *   variant     0 = auto, 1 = generic persistent kernel, 2 = register/LDS-resident BL6-class kernel,
  *               3 = stepped multi-launch decode for large geometries (REF6),
  *               4 = cohort decode of large geometries: up to 64 utterances in lock step, lanes = utterances
- *                   (explicit only; auto keeps the stepped decode)                                            */
+ *                   (explicit only; auto keeps the stepped decode),
+ *               5 = cluster decode of large geometries: ONE persistent launch, the CUs of an XCD carry an utterance
+ *                   through every phase and hand the hidden vectors to one another as tagged 8-byte granules
+ *                   (6-layer stacks with K = 3 | 7, H <= 256; explicit only).  It needs every workgroup of its grid
+ *                   resident at once; if they are not, it gives up within seconds and fills out_dev with NaN / -1   */
 typedef struct swn_decode_io {
     /* sampling noise.  noise_dev != NULL: the host-drawn stream (parity mode; the host draws it with the torch CPU
      * generator in the reference's order): laplace (B, n_steps, seg) uniform(-0.4999, 0.5) draws

@@ -1,26 +1,35 @@
 // Cluster decode for LARGE geometries (reference-shipped REF6: H=192/256, K=7, 15-24 MB of weights per generated
 // sample) on gfx950: ONE persistent launch, the CUs of one XCD form a cluster that carries an utterance (or up to 8 of
 // them in lock step) through every phase of every step, handing the H-vector of each layer to one another through
-// memory with flags - SURVEY.md 7.3 option (i).
+// memory - SURVEY.md 7.3 option (i).
 //
 // Why: the stepped decode (swn_decode_stepped.hip) pays a kernel boundary plus two memory round trips per phase,
-// 3.3-4.2 us x (L+3) launches per generated step.  Here a phase boundary is a cluster barrier (agent-scope atomic add
-// + sc1 poll, ~1-1.5 us), the dil_h weight rows of the NEXT layer stream into registers while the current phase waits,
-// and sampling / out_2 / the input layer are evaluated redundantly by every CU, so they need no hand-off at all.
+// 3.3-4.2 us x (L+3) launches per generated step.  Here
+//   * a hand-off is ONE round trip: every handed-off value travels as an 8-byte granule {value, tag} written with a
+//     write-through (sc1) store, and the consumer's sc1 load of the very data it needs is the poll - no barrier, no
+//     flag, no second load (MI355X_MICROARCH.md "handoff-1to1": 0.8-1.0 us against 1.7-2.5x that for flag + payload);
+//   * the dil_h rows a CU owns stay in its registers for the whole launch where they fit (REF6 Laplace: 378 of the 512
+//     registers of a one-wave-per-SIMD lane), otherwise they stream two layers ahead;
+//   * everything that does not depend on the hand-off (the K-1 old taps, conditioning, biases) is fetched before the
+//     poll; sampling / out_2 / the input layer are evaluated redundantly by every CU and need no hand-off at all.
 //
 //   cluster     = the workgroups (one per CU, forced by the LDS request) that report the same HW_REG_XCC_ID; each takes
 //                 a slot from a per-XCD ticket.  Nothing depends on the dispatch order.
 //   partition   = slot s owns hidden channels [s*CPC, (s+1)*CPC) of every layer (gate + candidate rows), SPC rows of
 //                 the concatenated out_skip 1x1 and OPC rows of out_1 (and of out_2 when it is wide: softmax).
-//   hand-off    = producer: sc1 (write-through) stores -> every wave s_waitcnt vmcnt(0) -> workgroup barrier -> one
-//                 agent-scope atomic add; consumer: one lane polls with sc1 loads, workgroup barrier, then every load of
-//                 handed-off bytes is an sc1 buffer load (MI355X_MICROARCH.md "inter-workgroup visibility", first table row).
+//   tags        = iteration number + 1 (never 0: the state block starts zeroed).  A mailbox slot is written once per
+//                 iteration; its next writer has, through the dependency chain of the phases, consumed something
+//                 every reader of the old value produced after reading it, so no value is overwritten unread.  The
+//                 float rings (old taps) take the same stores one instruction earlier: stores of a wave complete in
+//                 order, so a reader that saw a later granule of a producer sees its ring stores too; rings carry seg
+//                 spare slots because clusters may be one iteration apart.
 //   safety      = every poll loop is bounded; a cluster that cannot assemble (workgroups not co-resident) raises the
-//                 abort word, every workgroup leaves at its next barrier and the outputs of the launch are filled with
+//                 abort word, every workgroup leaves at its next poll and the outputs of the launch are filled with
 //                 NaN / -1 so that the failure cannot pass for a result.
 // The math, the ring layout and the noise are those of swn_decode.hip / swn_decode_stepped.hip (cswnv_shift1.py:281-430,
 // dswnv.py:290-399).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "swn_geom.hpp"
 #include "swn_noise.hpp"
 
@@ -31,12 +40,13 @@ constexpr int UBM = 8;               // utterances a cluster carries in lock ste
 constexpr int NXCD = 8;
 constexpr int CPC_MAX = 8;           // channels per CU (H <= 256 on >= 32 CUs)
 constexpr int SEG_MAX = 10;
-constexpr unsigned SPIN_LIMIT = 1u << 21;
+constexpr int LL = 6;                // stack depth this kernel is unrolled for
+constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr unsigned SC1 = 16;         // buffer-instruction cache policy bit: sc1
 constexpr unsigned CL_OOB = 0x80000000u;
 
 // control words, each on a 128-byte line of its own (32 uints apart)
-enum { CW_TICKET = 0, CW_BAR = 8, CW_ARRIVED = 16, CW_ABORT = 17, CW_COUNT = 18 };
+enum { CW_TICKET = 0, CW_ARRIVED = 8, CW_ABORT = 9, CW_COUNT = 10 };
 constexpr int CW_STRIDE = 32;
 
 struct ClArgs {
@@ -45,8 +55,9 @@ struct ClArgs {
     const float* P; const float* cond; SwnNoise nz; const void* forced; const void* seed;
     float* state; void* out; float* heads; unsigned* ctrl;
     int B, Tf, n_steps, n_pro, WN;
-    int ring_off[SWN_MAXL], ring_len[SWN_MAXL];      // ring l (l >= 1): input history of layer l, in the state block
-    int o_hlast, o_skip, o_o1, o_o2, stride;         // per-utterance float offsets in the state block
+    int ring_off[SWN_MAXL], ring_len[SWN_MAXL];      // float ring l (l >= 1): input history of layer l (old taps)
+    int mb_off[SWN_MAXL];                            // granule mailbox of layer l's OUTPUT: [seg][Hp] x {value, tag}
+    int o_ms, o_m1, o_m2, stride;                    // granule vectors skip[Sp], out_1[O1p], out_2[NO]; per-utterance floats
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -54,17 +65,22 @@ __device__ __forceinline__ int pmod(int r, int m) { int t = r % m; return t < 0 
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t cl_rsrc(const void* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ float4 ld4(__amdgpu_buffer_rsrc_t r, unsigned off) {           // plain (read-only data)
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+__device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {             // plain (read-only data)
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
-__device__ __forceinline__ float4 ld4_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {       // handed-off data
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, SC1));
-}
-__device__ __forceinline__ float ld1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+__device__ __forceinline__ float ld1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {         // handed-off data
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, SC1));
+}
+__device__ __forceinline__ uint2 ldg_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {         // one granule {value, tag}
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, SC1));
 }
 __device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, SC1);
+}
+__device__ __forceinline__ void stg_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float v, unsigned tag) {
+    typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    u2 gr; gr.x = __builtin_bit_cast(unsigned, v); gr.y = tag;
+    __builtin_amdgcn_raw_buffer_store_b64(gr, r, off, 0, SC1);
 }
 __device__ __forceinline__ float sum64(float v) {
     v += __shfl_xor(v, 32, 64); v += __shfl_xor(v, 16, 64); v += __shfl_xor(v, 8, 64); v += __shfl_xor(v, 4, 64);
@@ -87,15 +103,17 @@ __device__ __forceinline__ bool wait_ge(const unsigned* p, unsigned target, unsi
     return true;
 }
 
-// NI = float4 pieces per lane and row (ceil(K*Hp / 256)), RW = rows per wave, KIND
-template <int NI, int RW, int KIND>
+// CL = channels per lane (ceil(H / 64)), KT = kernel size, RW = rows per wave, NSET = register sets for the dil_h rows
+// (LL: resident; 3: streamed two layers ahead)
+template <int CL, int KT, int RW, int NSET, int KIND>
 __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     __shared__ int s_dead;
     __shared__ unsigned s_tickets[NXCD];
     const SwnGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int H = g.H, Hp = g.Hp, K = g.K, L = g.L, H2 = 2 * g.H, seg = g.seg, S = g.S, KH = K * Hp, WN = a.WN;
+    const int H = g.H, Hp = g.Hp, H2 = 2 * g.H, seg = g.seg, S = g.S, WN = a.WN;
+    constexpr int K = KT, L = LL;
     const float* __restrict__ P = a.P;
     unsigned* abortw = a.ctrl + CW_ABORT * CW_STRIDE;
 
@@ -118,8 +136,6 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
     int ncl = 0, cidx = 0;
     for (int x = 0; x < NXCD; ++x) { if (s_tickets[x] > 0) { if (x < (int)xcc) ++cidx; ++ncl; } }
     const int NC = (int)s_tickets[xcc];
-    unsigned* bar = a.ctrl + (CW_BAR + xcc) * CW_STRIDE;
-    unsigned bar_k = 0;                                     // barriers passed by this cluster
 
     // partition of the rows over the cluster
     const int CPC = (H + NC - 1) / NC;
@@ -132,6 +148,7 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
     const int OPC = (g.O1 + NC - 1) / NC, or0 = slot * OPC, nor = or0 < g.O1 ? (g.O1 - or0 < OPC ? g.O1 - or0 : OPC) : 0;
     const bool wide = g.NO > 64;                             // softmax: out_2 rows are distributed like out_1's
     const int NPC = (g.NO + NC - 1) / NC, nr0 = slot * NPC, nnr = nr0 < g.NO ? (g.NO - nr0 < NPC ? g.NO - nr0 : NPC) : 0;
+    if (SPC > 8) { if (tid == 0) astore(abortw, 3u); return; }       // two skip rows per wave
     // utterances of this cluster: b = cidx, cidx + ncl, ...  ; a pass carries up to UBM of them
     const int n_mine = a.B > cidx ? (a.B - cidx + ncl - 1) / ncl : 0;
 
@@ -139,44 +156,59 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
     const int R0 = a.ring_len[0];
     float* ring0 = lds;                                      // [UBM][R0][Hp]  local history of the input layer
     float* rsum = ring0 + UBM * R0 * Hp;                     // [UBM][SEG_MAX][2*CPC_MAX] gate / candidate row sums
-    float* win = rsum + UBM * SEG_MAX * 2 * CPC_MAX;         // [UBM][32] sample windows (float samples | int classes)
+    float* hpv = rsum + UBM * SEG_MAX * 2 * CPC_MAX;         // [UBM][SEG_MAX][CPC_MAX]   highway inputs of the own channels
+    float* win = hpv + UBM * SEG_MAX * CPC_MAX;              // [UBM][32] sample windows (float samples | int classes)
     float* o2v = win + UBM * 32;                             // [UBM][round4(NO)]
-    float* vec = o2v + UBM * swn_round4(g.NO);               // [UBM][max(Sp, O1p)] staging of a full skip / out_1 vector
+    float* vec = o2v + UBM * swn_round4(g.NO);               // [UBM][512] staging of a full skip / out_1 vector
+    float* skl = vec + UBM * 512;                            // [UBM][4 waves][2 rows][64 lanes] lane-partial out_skip sums
     int* iwin = reinterpret_cast<int*>(win);
 
     const __amdgpu_buffer_rsrc_t rP = cl_rsrc(P), rS = cl_rsrc(a.state);
-    auto cluster_barrier = [&]() -> bool {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's sc1 stores have left
-        __syncthreads();
-        ++bar_k;
-        if (tid == 0) {
-            aadd(bar, 1u);
-            if (!wait_ge(bar, (unsigned)NC * bar_k, abortw)) s_dead = 1;
+    const int c_lo = lane * CL;                              // this lane's channels c_lo .. c_lo+CL-1 of every H-vector
+    unsigned spins_total = 0;
+    auto give_up = [&]() __attribute__((always_inline)) { astore(abortw, 1u); s_dead = 1; };
+
+    // CL granules of an H-vector mailbox at float offset `off` (+ this lane's channels): poll until every tag == tag.
+    // Returns false when the launch is aborting.
+    auto poll_vec = [&](size_t off, unsigned tag, float (&v)[CL]) __attribute__((always_inline)) -> bool {
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                const bool live = c_lo + c < Hp;
+                const uint2 gr = ldg_sc1(rS, live ? (unsigned)((off + 2 * (size_t)(c_lo + c)) * 4) : CL_OOB);
+                v[c] = __builtin_bit_cast(float, gr.x);
+                ok = ok && (!live || gr.y == tag);
+            }
+            if (__all(ok)) return true;
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > SPIN_LIMIT) { give_up(); return false; }
+            if ((spins & 255u) == 0u && aload(abortw) != 0u) { s_dead = 1; return false; }
         }
-        __syncthreads();
-        return s_dead == 0;
     };
 
-    // weight rows of layer l for this wave: rows rw -> local row index w*RW + rw -> channel ch0 + (idx >> 1), gate | cand
-    float4 wcur[RW][NI], wnext[RW][NI];
-    auto load_rows = [&](int l, float4 (&dst)[RW][NI]) {
+    // dil_h rows of this wave: local row lr = w*RW + rw -> channel ch0 + (lr >> 1), gate | candidate
+    float wr[NSET][RW][KT][CL];
+    auto load_rows = [&](int l, float (&dst)[RW][KT][CL]) __attribute__((always_inline)) {
 #pragma unroll
         for (int rw = 0; rw < RW; ++rw) {
             const int lr = w * RW + rw, c = lr >> 1;
             const bool live = c < nch;
             const size_t row = (size_t)l * H2 + (lr & 1 ? H : 0) + ch0 + c;
 #pragma unroll
-            for (int pc = 0; pc < NI; ++pc) {
-                const int idx = pc * 256 + lane * 4;
-                dst[rw][pc] = ld4(rP, (live && idx < KH) ? (unsigned)((a.y.wd + row * KH + idx) * 4) : CL_OOB);
-            }
+            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                for (int cc = 0; cc < CL; ++cc)
+                    dst[rw][k][cc] = ld1(rP, (live && c_lo + cc < Hp) ? (unsigned)((a.y.wd + (row * K + k) * Hp + c_lo + cc) * 4) : CL_OOB);
         }
     };
 
+    unsigned tag_base = 0;
     for (int pass0 = 0; pass0 < n_mine; pass0 += UBM) {
         const int UB = n_mine - pass0 < UBM ? n_mine - pass0 : UBM;
-        auto utt = [&](int u) { return cidx + (pass0 + u) * ncl; };           // global utterance index
-        // ---- per-pass initialisation: local rings and sample windows (the global rings were zeroed by the host)
+        auto utt = [&](int u) __attribute__((always_inline)) { return cidx + (pass0 + u) * ncl; };           // global utterance index
+        // ---- per-pass initialisation: local rings and sample windows (the global state was zeroed by the host)
         for (int e = tid; e < UBM * R0 * Hp; e += NT) ring0[e] = 0.f;
         for (int e = tid; e < UBM * 32; e += NT) {
             const int u = e >> 5, k = e & 31;
@@ -191,7 +223,10 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
             }
         }
         __syncthreads();
-        load_rows(0, wcur);
+        if (pass0 == 0 || NSET < L) {
+#pragma unroll
+            for (int l = 0; l < (NSET < L ? 2 : L); ++l) load_rows(l, wr[l % NSET]);      // resident: once; streamed: layers 0, 1
+        }
 
         const int total = a.n_pro + a.n_steps;
         for (int it = 0; it < total; ++it) {
@@ -199,6 +234,7 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
             const int i = it - a.n_pro, np = gen ? seg : 1;
             const int q0 = gen ? g.rf + 1 - seg + i * seg : it;
             const int nl = gen ? L : L - 1;                  // the prologue never needs the last layer's output
+            const unsigned tag = tag_base + (unsigned)it + 1u;
 
             // ---- input layer (every CU, every channel): h0 -> local ring (cswnv_shift1.py:352 / dswnv.py:345)
             for (int e = tid; e < UB * np * H; e += NT) {
@@ -225,76 +261,39 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
             }
             __syncthreads();
 
-            float sacc[UBM][2];                              // this wave's (<= 2) skip rows, lane-partial, per utterance
-#pragma unroll
-            for (int u = 0; u < UBM; ++u) { sacc[u][0] = 0.f; sacc[u][1] = 0.f; }
-            // skip contribution of hidden state `hl` (layer index l = 1..L: columns (l-1)*Hp ..) at the step's last position
-            auto skip_add = [&](int l, int src_ring, bool from_hlast) {
-                const int q = q0 + np - 1;
+            // this wave's (<= 2) out_skip rows, lane-partial, per utterance: private LDS words of the lane
+            if (gen) for (int u = 0; u < UB; ++u) { skl[((u * 4 + w) * 2 + 0) * 64 + lane] = 0.f; skl[((u * 4 + w) * 2 + 1) * 64 + lane] = 0.f; }
+            // out_skip share of hidden state h_l (l = 1..L, column block l-1), held by the lanes as x[CL]
+            auto skip_add = [&](int l, int u, const float (&x)[CL]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int lr = w * 2 + rr;
                     const bool live = lr < nsr;
-                    for (int c0 = lane * 4; c0 < Hp; c0 += 256) {
-                        const float4 wv = ld4(rP, live ? (unsigned)((a.y.wsk + (size_t)(sr0 + lr) * L * Hp + (size_t)(l - 1) * Hp + c0) * 4) : CL_OOB);
+                    float acc = skl[((u * 4 + w) * 2 + rr) * 64 + lane];
 #pragma unroll
-                        for (int u = 0; u < UBM; ++u) {
-                            if (u < UB) {
-                                const size_t base = (size_t)utt(u) * a.stride +
-                                    (from_hlast ? (size_t)a.o_hlast : (size_t)a.ring_off[src_ring] + (size_t)pmod(q, a.ring_len[src_ring]) * Hp);
-                                const float4 x = ld4_sc1(rS, (unsigned)((base + c0) * 4));
-                                sacc[u][rr] = fmaf(wv.x, x.x, sacc[u][rr]); sacc[u][rr] = fmaf(wv.y, x.y, sacc[u][rr]);
-                                sacc[u][rr] = fmaf(wv.z, x.z, sacc[u][rr]); sacc[u][rr] = fmaf(wv.w, x.w, sacc[u][rr]);
-                            }
-                        }
+                    for (int c = 0; c < CL; ++c) {
+                        const float wv = ld1(rP, (live && c_lo + c < Hp) ? (unsigned)((a.y.wsk + (size_t)(sr0 + lr) * L * Hp + (size_t)(l - 1) * Hp + c_lo + c) * 4) : CL_OOB);
+                        acc = fmaf(wv, x[c], acc);
                     }
+                    skl[((u * 4 + w) * 2 + rr) * 64 + lane] = acc;
                 }
             };
 
-            // ---- stack
-            for (int l = 0; l < nl; ++l) {
-                const int nxt = (l + 1 < nl) ? l + 1 : 0;    // the layer whose rows stream in under this phase
-                load_rows(nxt, wnext);
+            // ---- stack: one phase per layer, unrolled so that the register sets are named statically
+            bool alive = true;
+            auto phase = [&](auto lc) __attribute__((always_inline)) {
+                constexpr int l = decltype(lc)::value;
+                if (!alive || l >= nl) return;
                 const int dil = g.dil[l], R = a.ring_len[l];
-                for (int u = 0; u < UB; ++u) {
-                    const size_t ub = (size_t)utt(u) * a.stride;
-                    for (int j = 0; j < np; ++j) {
-                        const int q = q0 + j;
-                        float4 xv[NI];
-#pragma unroll
-                        for (int pc = 0; pc < NI; ++pc) {
-                            const int idx = pc * 256 + lane * 4;
-                            const int ic = idx < KH ? idx : 0;
-                            const int tap = ic / Hp, ii = ic - tap * Hp;
-                            const int slotp = pmod(q - (K - 1 - tap) * dil, R);
-                            if (l == 0) {
-                                xv[pc] = idx < KH ? *reinterpret_cast<const float4*>(ring0 + (u * R0 + slotp) * Hp + ii)
-                                                  : make_float4(0.f, 0.f, 0.f, 0.f);
-                            } else {
-                                xv[pc] = ld4_sc1(rS, idx < KH ? (unsigned)((ub + a.ring_off[l] + (size_t)slotp * Hp + ii) * 4) : CL_OOB);
-                            }
-                        }
-#pragma unroll
-                        for (int rw = 0; rw < RW; ++rw) {
-                            float acc = 0.f;
-#pragma unroll
-                            for (int pc = 0; pc < NI; ++pc) {
-                                acc = fmaf(wcur[rw][pc].x, xv[pc].x, acc); acc = fmaf(wcur[rw][pc].y, xv[pc].y, acc);
-                                acc = fmaf(wcur[rw][pc].z, xv[pc].z, acc); acc = fmaf(wcur[rw][pc].w, xv[pc].w, acc);
-                            }
-                            acc = sum64(acc);
-                            if (lane == 0) rsum[(u * SEG_MAX + j) * 2 * CPC_MAX + w * RW + rw] = acc;
-                        }
-                    }
-                }
-                if (gen && l >= 1) skip_add(l, l, false);    // h_l (input of this layer) is visible: its out_skip share
-                __syncthreads();
-                // gate epilogue: one thread per (utterance, position, own channel)
-                for (int e = tid; e < UB * np * nch; e += NT) {
-                    const int c = e % nch, j = (e / nch) % np, u = e / (nch * np);
-                    const int o = ch0 + c, q = q0 + j, b = utt(u);
-                    const size_t ub = (size_t)b * a.stride;
-                    float gz = P[a.y.bx + (size_t)l * H2 + o], gc = P[a.y.bx + (size_t)l * H2 + H + o];
+                float (&wl)[RW][KT][CL] = wr[l % NSET];
+                // epilogue operands of the own channels: nothing here depends on the hand-off
+                float e_gz = 0.f, e_gc = 0.f, e_bz = 0.f, e_bc = 0.f;
+                const bool epi = tid < UB * np * nch;
+                int e_c = 0, e_j = 0, e_u = 0;
+                if (epi) {
+                    e_c = tid % nch; e_j = (tid / nch) % np; e_u = tid / (nch * np);
+                    const int o = ch0 + e_c, q = q0 + e_j, b = utt(e_u);
+                    e_gz = P[a.y.bx + (size_t)l * H2 + o]; e_gc = P[a.y.bx + (size_t)l * H2 + H + o];
                     const float* condb = a.cond + (size_t)b * a.Tf * g.N;
                     for (int s = 0; s < seg; ++s) {
                         int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
@@ -302,57 +301,125 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                         f = f < a.Tf ? f : a.Tf - 1;
                         const float wu = P[a.y.wup + jj];
                         const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
-                        gz = fmaf(wu, cr[o], gz); gc = fmaf(wu, cr[H + o], gc);
+                        e_gz = fmaf(wu, cr[o], e_gz); e_gc = fmaf(wu, cr[H + o], e_gc);
                     }
-                    const float az = rsum[(u * SEG_MAX + j) * 2 * CPC_MAX + 2 * c] + P[a.y.bd + (size_t)l * H2 + o];
-                    const float ac = rsum[(u * SEG_MAX + j) * 2 * CPC_MAX + 2 * c + 1] + P[a.y.bd + (size_t)l * H2 + H + o];
-                    const float hp = l == 0 ? ring0[(u * R0 + pmod(q, R0)) * Hp + o]
-                                            : ld1_sc1(rS, (unsigned)((ub + a.ring_off[l] + (size_t)pmod(q, R) * Hp + o) * 4));
-                    const float z = sigm(gz * az);
-                    const float cd = tanhf(gc * ac);
-                    const float hn = (1.f - z) * cd + z * hp;
-                    if (l + 1 < L) st1_sc1(rS, (unsigned)((ub + a.ring_off[l + 1] + (size_t)pmod(q, a.ring_len[l + 1]) * Hp + o) * 4), hn);
-                    else if (j == np - 1) st1_sc1(rS, (unsigned)((ub + a.o_hlast + o) * 4), hn);
+                    e_bz = P[a.y.bd + (size_t)l * H2 + o]; e_bc = P[a.y.bd + (size_t)l * H2 + H + o];
                 }
-                if (!cluster_barrier()) return;
+                for (int u = 0; u < UB && alive; ++u) {
+                    const size_t ub = (size_t)utt(u) * a.stride;
+                    for (int j = 0; j < np && alive; ++j) {
+                        const int q = q0 + j;
+                        float x[KT][CL];
+                        // the K-1 older taps first (float ring / local ring: all of them are visible - a position of this
+                        // very iteration was polled as the newest tap of an earlier j, and its ring store precedes its
+                        // granule in the storing thread), then the hand-off: the newest tap
 #pragma unroll
-                for (int rw = 0; rw < RW; ++rw)
+                        for (int k = 0; k < KT - (l > 0 ? 1 : 0); ++k) {
+                            const int pos = q - (K - 1 - k) * dil;
 #pragma unroll
-                    for (int pc = 0; pc < NI; ++pc) wcur[rw][pc] = wnext[rw][pc];
-            }
+                            for (int c = 0; c < CL; ++c) {
+                                if (l == 0) x[k][c] = c_lo + c < Hp ? ring0[(u * R0 + pmod(pos, R0)) * Hp + c_lo + c] : 0.f;
+                                else x[k][c] = ld1_sc1(rS, c_lo + c < Hp ? (unsigned)((ub + a.ring_off[l] + (size_t)pmod(pos, R) * Hp + c_lo + c) * 4) : CL_OOB);
+                            }
+                        }
+                        if (l > 0) {
+                            if (!poll_vec(ub + a.mb_off[l - 1] + 2 * (size_t)j * Hp, tag, x[KT - 1])) { alive = false; break; }
+                        }
+                        // highway inputs of the own channels: the lanes that hold them publish them for the epilogue
+                        if (w == 0) {
+#pragma unroll
+                            for (int c = 0; c < CL; ++c) {
+                                const int o = c_lo + c - ch0;
+                                if (o >= 0 && o < nch) hpv[(u * SEG_MAX + j) * CPC_MAX + o] = x[KT - 1][c];
+                            }
+                        }
+                        if (gen && l >= 1 && j == np - 1) skip_add(l, u, x[KT - 1]);       // h_l at the step's last position
+#pragma unroll
+                        for (int rw = 0; rw < RW; ++rw) {
+                            float acc = 0.f;
+#pragma unroll
+                            for (int k = 0; k < KT; ++k)
+#pragma unroll
+                                for (int c = 0; c < CL; ++c) acc = fmaf(wl[rw][k][c], x[k][c], acc);
+                            acc = sum64(acc);
+                            if (lane == 0) rsum[(u * SEG_MAX + j) * 2 * CPC_MAX + w * RW + rw] = acc;
+                        }
+                    }
+                }
+                // streamed rows: the layer two phases ahead takes the set the previous layer has finished with (set of
+                // layer x = x % 3; a prologue iteration runs L-1 layers, a generation step L)
+                if (NSET < L) {
+                    if (gen) { constexpr int nx = (l + 2) % L; load_rows(nx, wr[nx % NSET]); }
+                    else { constexpr int nx = (l + 2) % (L - 1); load_rows(nx, wr[nx % NSET]); }
+                }
+                __syncthreads();
+                if (!alive || s_dead) { alive = false; return; }
+                if (epi) {
+                    const int o = ch0 + e_c, q = q0 + e_j;
+                    const size_t ub = (size_t)utt(e_u) * a.stride;
+                    const float az = rsum[(e_u * SEG_MAX + e_j) * 2 * CPC_MAX + 2 * e_c] + e_bz;
+                    const float ac = rsum[(e_u * SEG_MAX + e_j) * 2 * CPC_MAX + 2 * e_c + 1] + e_bc;
+                    const float hp = hpv[(e_u * SEG_MAX + e_j) * CPC_MAX + e_c];
+                    const float z = sigm(e_gz * az);
+                    const float cd = tanhf(e_gc * ac);
+                    const float hn = (1.f - z) * cd + z * hp;
+                    // float ring first (old taps of later iterations), then the granule: stores of a wave complete in order
+                    if (l + 1 < L) st1_sc1(rS, (unsigned)((ub + a.ring_off[l + 1] + (size_t)pmod(q, a.ring_len[l + 1]) * Hp + o) * 4), hn);
+                    stg_sc1(rS, (unsigned)((ub + a.mb_off[l] + 2 * ((size_t)e_j * Hp + o)) * 4), hn, tag);
+                }
+                __syncthreads();                             // rsum / hpv are reused by the next phase
+            };
+            phase(std::integral_constant<int, 0>{}); phase(std::integral_constant<int, 1>{});
+            phase(std::integral_constant<int, 2>{}); phase(std::integral_constant<int, 3>{});
+            phase(std::integral_constant<int, 4>{}); phase(std::integral_constant<int, 5>{});
+            if (!alive || s_dead) return;
             if (!gen) continue;
 
-            // ---- head: out_skip (finish) -> relu -> out_1 -> relu -> out_2
-            skip_add(L, 0, true);
+            // ---- head: out_skip (finish with h_L) -> relu -> out_1 -> relu -> out_2
+            for (int u = 0; u < UB; ++u) {
+                float x[CL];
+                if (!poll_vec((size_t)utt(u) * a.stride + a.mb_off[L - 1] + 2 * (size_t)(np - 1) * Hp, tag, x)) return;
+                skip_add(L, u, x);
+            }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
                 const int lr = w * 2 + rr;
-#pragma unroll
-                for (int u = 0; u < UBM; ++u) {
-                    if (u < UB) {
-                        const float v = sum64(sacc[u][rr]);
-                        if (lane == 0 && lr < nsr)
-                            st1_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + a.o_skip + sr0 + lr) * 4), fmaxf(v + P[a.y.bsk + sr0 + lr], 0.f));
-                    }
+                for (int u = 0; u < UB; ++u) {
+                    const float v = sum64(skl[((u * 4 + w) * 2 + rr) * 64 + lane]);
+                    if (lane == 0 && lr < nsr)
+                        stg_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + a.o_ms + 2 * (size_t)(sr0 + lr)) * 4),
+                                fmaxf(v + P[a.y.bsk + sr0 + lr], 0.f), tag);
                 }
             }
-            if (!cluster_barrier()) return;
-            // rows x vector products of the head: the full input vector is staged in LDS once per utterance
-            auto stage_vec = [&](int off, int n4) {          // n4 = padded length in floats (multiple of 4)
-                for (int e = tid; e < UB * (n4 >> 2); e += NT) {
-                    const int u = e / (n4 >> 2), c4 = e - u * (n4 >> 2);
-                    *reinterpret_cast<float4*>(vec + u * 512 + 4 * c4) = ld4_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + off + 4 * c4) * 4));
+            // full vector of n granules -> LDS staging; thread e polls granule e (n <= 512 -> two per thread at most)
+            auto stage_vec = [&](int off, int n) __attribute__((always_inline)) -> bool {
+                bool ok_all = true;
+                for (int e = tid; e < UB * 512; e += NT) {
+                    const int u = e >> 9, c = e & 511;
+                    if (c < n) {
+                        unsigned spins = 0;
+                        for (;;) {
+                            const uint2 gr = ldg_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + off + 2 * (size_t)c) * 4));
+                            if (gr.y == tag) { vec[u * 512 + c] = __builtin_bit_cast(float, gr.x); break; }
+                            __builtin_amdgcn_s_sleep(1);
+                            if (++spins > SPIN_LIMIT) { give_up(); ok_all = false; break; }
+                            if ((spins & 255u) == 0u && aload(abortw) != 0u) { s_dead = 1; ok_all = false; break; }
+                        }
+                    } else {
+                        vec[u * 512 + c] = 0.f;
+                    }
                 }
                 __syncthreads();
+                return ok_all && !s_dead;
             };
-            auto rows_times_vec = [&](size_t w_off, int ldw, size_t b_off, int r0, int nrows, int nin, int y_off, bool relu, bool to_lds) {
-                // wave w takes local rows w, w+4, ...; lanes split the inputs
-                for (int lr = w; lr < nrows; lr += 4) {
+            // rows [r0, r0 + nrows) of W (ld ldw, nin inputs) times the staged vectors; result: granule mailbox | LDS
+            auto rows_times_vec = [&](size_t w_off, int ldw, size_t b_off, int r0, int nrows, int nin, int y_off, bool relu, bool to_lds) __attribute__((always_inline)) {
+                for (int lr = w; lr < nrows; lr += 4) {       // wave w takes local rows w, w+4, ...; lanes split the inputs
                     float acc[UBM];
 #pragma unroll
                     for (int u = 0; u < UBM; ++u) acc[u] = 0.f;
                     for (int c0 = lane * 4; c0 < nin; c0 += 256) {
-                        const float4 wv = ld4(rP, (unsigned)((w_off + (size_t)(r0 + lr) * ldw + c0) * 4));
+                        const float4 wv = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rP, (unsigned)((w_off + (size_t)(r0 + lr) * ldw + c0) * 4), 0, 0));
 #pragma unroll
                         for (int u = 0; u < UBM; ++u) {
                             if (u < UB) {
@@ -370,22 +437,23 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                                 v += P[b_off + r0 + lr];
                                 v = relu ? fmaxf(v, 0.f) : v;
                                 if (to_lds) o2v[u * swn_round4(g.NO) + r0 + lr] = v;
-                                else st1_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + y_off + r0 + lr) * 4), v);
+                                else stg_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + y_off + 2 * (size_t)(r0 + lr)) * 4), v, tag);
                             }
                         }
                     }
                 }
             };
-            stage_vec(a.o_skip, g.Sp);
-            rows_times_vec(a.y.w1, g.Sp, a.y.b1, or0, nor, g.Sp, a.o_o1, true, false);
-            if (!cluster_barrier()) return;
-            stage_vec(a.o_o1, g.O1p);
+            if (!stage_vec(a.o_ms, S)) return;
+            rows_times_vec(a.y.w1, g.Sp, a.y.b1, or0, nor, g.Sp, a.o_m1, true, false);
+            __syncthreads();
+            if (!stage_vec(a.o_m1, g.O1)) return;
             if (wide) {
-                rows_times_vec(a.y.w2, g.O1p, a.y.b2, nr0, nnr, g.O1p, a.o_o2, false, false);
-                if (!cluster_barrier()) return;
+                rows_times_vec(a.y.w2, g.O1p, a.y.b2, nr0, nnr, g.O1p, a.o_m2, false, false);
+                __syncthreads();
+                if (!stage_vec(a.o_m2, g.NO)) return;
                 for (int e = tid; e < UB * g.NO; e += NT) {
                     const int u = e / g.NO, r = e - u * g.NO;
-                    o2v[u * swn_round4(g.NO) + r] = ld1_sc1(rS, (unsigned)(((size_t)utt(u) * a.stride + a.o_o2 + r) * 4));
+                    o2v[u * swn_round4(g.NO) + r] = vec[u * 512 + r];
                 }
             } else {
                 rows_times_vec(a.y.w2, g.O1p, a.y.b2, 0, g.NO, g.O1p, 0, false, true);      // every CU: all NO rows
@@ -463,8 +531,9 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
             }
             __syncthreads();
         }
-        if (!cluster_barrier()) return;                      // the next pass re-uses nothing of this one, but keep the clusters aligned
+        tag_base += (unsigned)total + 1u;
     }
+    (void)spins_total;
 }
 
 // fills the outputs with NaN / -1 when the launch aborted (runs after the decode kernel on the same stream)
@@ -479,30 +548,33 @@ __global__ void cluster_verdict_kernel(const unsigned* ctrl, void* out, size_t n
 int plan(ClArgs& a) {
     const SwnGeom& g = a.g;
     int o = 0;
-    for (int l = 0; l < g.L; ++l) { a.ring_off[l] = o; a.ring_len[l] = g.pad[l] + g.seg; o += a.ring_len[l] * g.Hp; }
+    // float rings carry seg spare slots: clusters run at most one iteration apart, and the producer of iteration t+1
+    // must not reach the oldest tap a consumer of iteration t still reads
+    for (int l = 0; l < g.L; ++l) { a.ring_off[l] = o; a.ring_len[l] = g.pad[l] + 2 * g.seg; if (l > 0) o += a.ring_len[l] * g.Hp; }
+    a.ring_len[0] = g.pad[0] + g.seg;                        // layer 0's history is local (LDS)
     a.WN = (g.K - 1 > g.lpc ? g.K - 1 : g.lpc) + g.seg;
-    a.o_hlast = o; o += g.Hp;
-    a.o_skip = o; o += g.Sp;
-    a.o_o1 = o; o += g.O1p;
-    a.o_o2 = o; o += swn_round4(g.NO);
+    for (int l = 0; l < g.L; ++l) { a.mb_off[l] = o; o += 2 * g.seg * g.Hp; }
+    a.o_ms = o; o += 2 * g.Sp;
+    a.o_m1 = o; o += 2 * g.O1p;
+    a.o_m2 = o; o += 2 * swn_round4(g.NO);
     a.stride = (o + 63) & ~63;
     return a.stride;
 }
 
 size_t lds_floats(const ClArgs& a) {
     const SwnGeom& g = a.g;
-    return (size_t)UBM * a.ring_len[0] * g.Hp + (size_t)UBM * SEG_MAX * 2 * CPC_MAX + UBM * 32 + (size_t)UBM * swn_round4(g.NO) +
-           (size_t)UBM * 512;
+    return (size_t)UBM * a.ring_len[0] * g.Hp + (size_t)UBM * SEG_MAX * 2 * CPC_MAX + (size_t)UBM * SEG_MAX * CPC_MAX + UBM * 32 +
+           (size_t)UBM * swn_round4(g.NO) + (size_t)UBM * 512 + (size_t)UBM * 4 * 2 * 64;
 }
 
-template <int NI, int RW>
+template <int CL, int KT, int RW, int NSET>
 int launch_cluster(const ClArgs& a, size_t lds, int grid, hipStream_t st) {
     if (a.g.kind == SWN_KIND_LAPLACE) {
-        auto k = decode_cluster_kernel<NI, RW, SWN_KIND_LAPLACE>;
+        auto k = decode_cluster_kernel<CL, KT, RW, NSET, SWN_KIND_LAPLACE>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SWN_E_LAUNCH;
         hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
     } else {
-        auto k = decode_cluster_kernel<NI, RW, SWN_KIND_SOFTMAX>;
+        auto k = decode_cluster_kernel<CL, KT, RW, NSET, SWN_KIND_SOFTMAX>;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return SWN_E_LAUNCH;
         hipLaunchKernelGGL(k, dim3(grid), dim3(NT), lds, st, a);
     }
@@ -525,9 +597,8 @@ extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, co
     if (rc < 0) return rc;
     const SwnGeom& g = a.g;
     plan(a);
-    const int ni = (g.K * g.Hp + 255) / 256;
-    if (ni > 8 || g.seg > SEG_MAX || g.lpc > 16 || a.WN > 32 || g.audio_in || g.Sp > 512 || g.O1p > 512 || g.H > 256 ||
-        (g.Hp & 3) || (g.Sp & 3))
+    if (g.L != LL || (g.K != 3 && g.K != 7) || g.H > 256 || g.seg > SEG_MAX || g.lpc > 16 || a.WN > 32 || g.audio_in ||
+        g.S > 512 || g.O1 > 512 || g.NO > 512)
         return SWN_E_UNSUPPORTED;
     if ((size_t)a.stride * batch * sizeof(float) >= (1ull << 31)) return SWN_E_UNSUPPORTED;     // 32-bit buffer offsets
     int dev = 0; hipDeviceProp_t prop;
@@ -535,7 +606,7 @@ extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, co
     const int grid = prop.multiProcessorCount;                // one workgroup per CU: every CU joins its XCD's cluster
     if (grid < 8 * 8) return SWN_E_UNSUPPORTED;
     const size_t lds = lds_floats(a) * sizeof(float);
-    // the LDS request also keeps a second workgroup off the CU (co-residency of the whole grid is what the barriers need)
+    // the LDS request also keeps a second workgroup off the CU (co-residency of the whole grid is what the polls need)
     const size_t lds_req = lds > 84 * 1024 ? lds : 84 * 1024;
     if (lds_req > 160 * 1024) return SWN_E_UNSUPPORTED;
     swn_make_layout(&a.g, &a.y);
@@ -546,21 +617,15 @@ extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, co
     hipStream_t st = (hipStream_t)stream_;
     if (hipMemsetAsync(state, 0, sizeof(float) * (((st_floats + 63) & ~(size_t)63) + (size_t)CW_COUNT * CW_STRIDE), st) != hipSuccess)
         return SWN_E_LAUNCH;
-    // rows per wave: 2 * ceil(H / (CUs per XCD)) rows over 4 waves
+    // channels per lane / rows per wave for an evenly filled chip (the kernel aborts loudly if its cluster came out smaller)
+    const int cl = (g.Hp + 63) / 64;
     const int cpc = (g.H + grid / 8 - 1) / (grid / 8);
     const int rw = (2 * cpc + 3) / 4;
-    if (rw > 4) return SWN_E_UNSUPPORTED;
-#define SWN_CL(NI_)                                                           \
-    do {                                                                      \
-        if (rw <= 1) rc = launch_cluster<NI_, 1>(a, lds_req, grid, st);       \
-        else if (rw == 2) rc = launch_cluster<NI_, 2>(a, lds_req, grid, st);  \
-        else if (rw == 3) rc = launch_cluster<NI_, 3>(a, lds_req, grid, st);  \
-        else rc = launch_cluster<NI_, 4>(a, lds_req, grid, st);               \
-    } while (0)
-    if (ni <= 1) SWN_CL(1);
-    else if (ni <= 6) SWN_CL(6);
-    else SWN_CL(8);
-#undef SWN_CL
+    if (g.seg * cpc * UBM > NT) return SWN_E_UNSUPPORTED;     // one epilogue thread per (utterance, position, own channel)
+    rc = SWN_E_UNSUPPORTED;
+    if (g.K == 3 && cl == 1 && rw <= 1) rc = launch_cluster<1, 3, 1, LL>(a, lds_req, grid, st);        // tiny fixtures (H <= 64)
+    else if (g.K == 7 && cl == 3 && rw <= 3) rc = launch_cluster<3, 7, 3, LL>(a, lds_req, grid, st);   // run.sh Laplace: rows resident
+    else if (g.K == 7 && cl == 4 && rw <= 4) rc = launch_cluster<4, 7, 4, 3>(a, lds_req, grid, st);    // run.sh softmax: rows streamed
     if (rc != SWN_OK) return rc;
     const size_t n_out = (size_t)batch * n_steps * (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg);
     hipLaunchKernelGGL(cluster_verdict_kernel, dim3(64), dim3(256), 0, st, a.ctrl, out, n_out, g.kind == SWN_KIND_SOFTMAX ? 1 : 0);
