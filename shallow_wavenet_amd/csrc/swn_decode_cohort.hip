@@ -266,6 +266,132 @@ __global__ __launch_bounds__(1024) void co_rowvec_kernel(const CoArgs a, size_t 
     }
 }
 
+
+// ---- exact-fp32 matrix-core form of the two contractions above (round 2) -------------------------------------------
+// A layer of a 64-utterance cohort is a real GEMM, D[2H rows][64 utterances] = Wd[2H][K*H] . X[K*H][64], and the
+// utterance-minor state IS its B operand: a ring slot is a contiguous [Hp][64] block.  v_mfma_f32_16x16x4_f32 multiplies
+// fp32 operands like an fmaf chain (parity kept); its operands come per lane straight from memory - A: 16 bytes of a
+// weight row (the four k of one 16-wide k group: the k order inside a group is permuted identically for A and B,
+// which a sum does not see), B: one float of four consecutive state rows - so nothing is broadcast out of LDS, which
+// is what bounded the VALU kernels above (16 waves x 168 ds_read_b128 per launch).
+//   workgroup = 32 rows (gate rows o0..o0+15 and their candidate rows | 32 consecutive rows) x 16 utterances x all of K;
+//   its 8 waves split K (16-wide k groups w, w+8, ...), every wave issues ALL its operand loads before its first MFMA
+//   (one memory latency per launch), the eight partial tiles meet in LDS and are summed in wave order (deterministic);
+//   the epilogue's operands (conditioning, biases, highway input) are requested at kernel entry and arrive meanwhile.
+typedef float co_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GW = 8;             // waves per workgroup = K slices
+constexpr int GMAX = 11;          // 16-wide k groups per wave held in registers (K*Hp <= 16 * 8 * 11 = 1408 per pass)
+
+struct CoGemm {
+    size_t w_off; int ldw;        // A[row][k] = P[w_off + row * ldw + k]
+    int rows;                     // rows of the product
+    int split;                    // > 0: row group g = rows g*16.. and split + g*16.. (gate | candidate); 0: rows g*32 .. g*32+31
+    int ktot;                     // K (multiple of 16)
+    int ring;                     // 1: k = tap * Hp + i addresses layer l's ring; 0: k addresses x_off + k
+    int x_off, y_off, relu;
+    size_t b_off;
+};
+
+template <int KIND, int EPI>      // EPI 0: gated-layer epilogue, 1: bias (+ relu) rows
+__global__ __launch_bounds__(64 * GW) void co_gemm_kernel(const CoArgs a, const CoGemm d, const int l, const int it) {
+    __shared__ __attribute__((aligned(16))) float red[GW][2][64][4];
+    const SwnGeom& g = a.g;
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rc = lane & 15, kq = lane >> 4;
+    const int grp = blockIdx.x >> 2, cb = blockIdx.x & 3, c = blockIdx.y;
+    if (c * CO + cb * 16 >= a.B) return;                       // no utterance in this column block
+    const int col = 16 * cb + rc;
+    const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg;
+    const float* P = a.P;
+    const __amdgpu_buffer_rsrc_t rP = co_rsrc(P);
+    const __amdgpu_buffer_rsrc_t rSt = co_rsrc(a.state + (size_t)c * a.stride * CO);
+    const Iter r = iter_of(a, it);
+    const int np = EPI == 0 ? r.np : 1;
+    const int lim = d.split ? d.split : d.rows;
+    const int ra = (d.split ? grp * 16 : grp * 32) + rc, rb = d.split ? d.split + grp * 16 + rc : grp * 32 + 16 + rc;
+    const bool oka = ra < lim, okb = d.split ? oka : rb < d.rows;
+    const int ngroups = d.ktot >> 4;
+    // epilogue role of this thread (threads 0..255 / 0..511): one output element each
+    const int e_row = EPI == 0 ? (tid >> 4) & 15 : tid >> 4, e_col = 16 * cb + (tid & 15);
+    const int e_b = c * CO + e_col;
+    const bool e_on = EPI == 0 ? tid < 256 && grp * 16 + e_row < H : grp * 32 + e_row < d.rows;
+    float* st = a.state + (size_t)c * a.stride * CO;
+    for (int j = 0; j < np; ++j) {
+        const int q = r.q0 + (EPI == 0 ? j : r.np - 1);
+        // ---- epilogue operands first: their latency hides under the operand stream
+        float e_gz = 0.f, e_gc = 0.f, e_bz = 0.f, e_bc = 0.f, e_hp = 0.f;
+        if (e_on) {
+            if (EPI == 0) {
+                const int o = grp * 16 + e_row;
+                e_gz = P[a.y.bx + (size_t)l * H2 + o]; e_gc = P[a.y.bx + (size_t)l * H2 + H + o];
+                e_bz = P[a.y.bd + (size_t)l * H2 + o]; e_bc = P[a.y.bd + (size_t)l * H2 + H + o];
+                e_hp = st[(size_t)(a.ring_off[l] + pmod(q, a.ring_len[l]) * Hp + o) * CO + e_col];
+                if (e_b < a.B) {
+                    const float* condb = a.cond + (size_t)e_b * a.Tf * g.N;
+                    for (int s = 0; s < seg; ++s) {
+                        int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
+                        int f = tt / g.U; const int jj = tt - f * g.U;
+                        f = f < a.Tf ? f : a.Tf - 1;
+                        const float wu = P[a.y.wup + jj];
+                        const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+                        e_gz = fmaf(wu, cr[o], e_gz); e_gc = fmaf(wu, cr[H + o], e_gc);
+                    }
+                }
+            } else {
+                e_bz = P[d.b_off + grp * 32 + e_row];
+            }
+        }
+        co_f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+        for (int g0 = w; g0 < ngroups; g0 += GW * GMAX) {      // REF6 Laplace: one pass
+            cf4 a0[GMAX], a1[GMAX];
+            float bv[GMAX][4];
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u) {
+                const int gi = g0 + u * GW;
+                const bool on = gi < ngroups;
+                const int k = 16 * gi + 4 * kq;                                  // this lane's four k: k .. k+3
+                a0[u] = __builtin_bit_cast(cf4, __builtin_amdgcn_raw_buffer_load_b128(rP, (on && oka) ? (unsigned)((d.w_off + (size_t)ra * d.ldw + k) * 4) : CO_OOB, 0, 0));
+                a1[u] = __builtin_bit_cast(cf4, __builtin_amdgcn_raw_buffer_load_b128(rP, (on && okb) ? (unsigned)((d.w_off + (size_t)rb * d.ldw + k) * 4) : CO_OOB, 0, 0));
+                int xrow;                                                        // state row of input k
+                if (d.ring) { const int tap = k / Hp, ii = k - tap * Hp; xrow = a.ring_off[l] + pmod(q - (K - 1 - tap) * g.dil[l], a.ring_len[l]) * Hp + ii; }
+                else xrow = d.x_off + k;
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) bv[u][jj] = co_ld1(rSt, on ? (unsigned)((((size_t)xrow + jj) * CO + col) * 4) : CO_OOB);
+            }
+#pragma unroll
+            for (int u = 0; u < GMAX; ++u)
+#pragma unroll
+                for (int jj = 0; jj < 4; ++jj) {
+                    acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u][jj], bv[u][jj], acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u][jj], bv[u][jj], acc1, 0, 0, 0);
+                }
+        }
+        *reinterpret_cast<co_f32x4*>(&red[w][0][lane][0]) = acc0;
+        *reinterpret_cast<co_f32x4*>(&red[w][1][lane][0]) = acc1;
+        __syncthreads();
+        if (e_on) {
+            // element (row, column) of a 16 x 16 tile lives in lane (row / 4) * 16 + column, component row % 4
+            const int t = EPI == 0 ? 0 : e_row >> 4, rr = e_row & 15;
+            const int sl = (rr >> 2) * 16 + (tid & 15), si = rr & 3;
+            float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < GW; ++ww) { v0 += red[ww][t][sl][si]; if (EPI == 0) v1 += red[ww][1][sl][si]; }
+            if (EPI == 0) {
+                const int o = grp * 16 + e_row;
+                const float z = sigm(e_gz * (v0 + e_bz));
+                const float cd = tanhf(e_gc * (v1 + e_bc));
+                const float hn = (1.f - z) * cd + z * e_hp;
+                if (l + 1 < g.L) st[(size_t)(a.ring_off[l + 1] + pmod(q, a.ring_len[l + 1]) * Hp + o) * CO + e_col] = hn;
+                if (j == np - 1) st[(size_t)(a.o_hcat + l * Hp + o) * CO + e_col] = hn;
+            } else {
+                const float v = v0 + e_bz;
+                st[(size_t)(d.y_off + grp * 32 + e_row) * CO + e_col] = d.relu ? fmaxf(v, 0.f) : v;
+            }
+        }
+        __syncthreads();                                         // red is reused by the next position
+    }
+}
+
 // ---- sampling + history update, lane = utterance.  Laplace: one wave; softmax: 4 waves split the classes ------
 template <int KIND>
 __global__ __launch_bounds__(256) void co_tail_kernel(const CoArgs a, const int it) {
@@ -377,6 +503,12 @@ int plan(CoArgs& a) {
 
 }  // namespace
 
+// geometries the matrix-core kernels take: every K a multiple of 16 (16 * GW * GMAX = 1408 inputs per pass: REF6 Laplace
+// layers in one pass, the H = 256 softmax layers in two)
+bool co_mfma_ok(const SwnGeom& g) {
+    return (g.Hp % 16 == 0) && (g.Sp % 16 == 0) && (g.O1p % 16 == 0) && !g.audio_in && g.Hp == g.H;
+}
+
 extern "C" size_t swn_decode_cohort_state_floats(const swn_net_desc* d, int batch) {
     CoArgs a;
     if (swn_make_geom(d, &a.g) < 0 || batch < 1) return 0;
@@ -400,6 +532,21 @@ extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, con
     const unsigned nco = (unsigned)((batch + CO - 1) / CO);
     if (hipMemsetAsync(state, 0, sizeof(float) * (size_t)a.stride * CO * nco, st) != hipSuccess) return SWN_E_LAUNCH;
     const bool lap = g.kind == SWN_KIND_LAPLACE;
+    const bool mfma = co_mfma_ok(g);
+    auto gemm = [&](int epi, size_t w_off, int ldw, int rows, int split, int ktot, int ring, int x_off,
+                    size_t b_off, int y_off, int relu, int l, int it) {
+        CoGemm d2;
+        d2.w_off = w_off; d2.ldw = ldw; d2.rows = rows; d2.split = split; d2.ktot = ktot; d2.ring = ring;
+        d2.x_off = x_off; d2.y_off = y_off; d2.relu = relu; d2.b_off = b_off;
+        const int groups = split ? (split + 15) / 16 : (rows + 31) / 32;
+        const dim3 gg((unsigned)(groups * 4), nco);             // x = row group * 4 + block of 16 utterances
+        if (epi == 0) {
+            if (lap) hipLaunchKernelGGL((co_gemm_kernel<SWN_KIND_LAPLACE, 0>), gg, dim3(64 * GW), 0, st, a, d2, l, it);
+            else hipLaunchKernelGGL((co_gemm_kernel<SWN_KIND_SOFTMAX, 0>), gg, dim3(64 * GW), 0, st, a, d2, l, it);
+        } else {
+            hipLaunchKernelGGL((co_gemm_kernel<SWN_KIND_LAPLACE, 1>), gg, dim3(64 * GW), 0, st, a, d2, l, it);
+        }
+    };
     if (!lap || seed) hipLaunchKernelGGL(co_seed_kernel, dim3(nco), dim3(CO), 0, st, a);
     // slice width per wave and tap (multiple of 4); the instantiated widths cover Hp <= 256 and K <= 8
     const int ipw = ((g.Hp + KS - 1) / KS + 3) & ~3;
@@ -429,6 +576,10 @@ extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, con
         if (lap) hipLaunchKernelGGL(co_in_kernel<SWN_KIND_LAPLACE>, dim3((g.H + 3) / 4, nco), dim3(256), 0, st, a, it);
         else hipLaunchKernelGGL(co_in_kernel<SWN_KIND_SOFTMAX>, dim3((g.H + 3) / 4, nco), dim3(256), 0, st, a, it);
         for (int l = 0; l < g.L; ++l) {
+            if (mfma) {     // D[2H][64] = Wd_l[2H][K*Hp] . X: one workgroup per (16 channel pairs, tap)
+                gemm(0, a.y.wd + (size_t)l * 2 * g.H * g.K * g.Hp, g.K * g.Hp, 2 * g.H, g.H, g.K * g.Hp, 1, 0, 0, 0, 0, l, it);
+                continue;
+            }
             const dim3 lg((g.H + PW - 1) / PW, nco);
 #define SWN_CO_LAYER(IP, TP_)                                                                                       \
             do {                                                                                                     \
@@ -442,12 +593,20 @@ extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, con
         }
         if (it < a.n_pro) continue;
         // row lengths are the padded ones (multiples of 4; the padding of weights and activations is zero)
-        hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.S + RW - 1) / RW, nco), dim3(1024), lds_rv(g.L * g.Hp), st, a, a.y.wsk, g.L * g.Hp, a.y.bsk,
-                           g.S, g.L * g.Hp, a.o_hcat, a.o_skip, 1);
-        hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.O1 + RW - 1) / RW, nco), dim3(1024), lds_rv(g.Sp), st, a, a.y.w1, g.Sp, a.y.b1,
-                           g.O1, g.Sp, a.o_skip, a.o_o1, 1);
-        hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.NO + RW - 1) / RW, nco), dim3(1024), lds_rv(g.O1p), st, a, a.y.w2, g.O1p, a.y.b2,
-                           g.NO, g.O1p, a.o_o1, a.o_o2, 0);
+        if (mfma) {
+            gemm(1, a.y.wsk, g.L * g.Hp, g.S, 0, g.L * g.Hp, 0, a.o_hcat, a.y.bsk, a.o_skip, 1, 0, it);
+            gemm(1, a.y.w1, g.Sp, g.O1, 0, g.Sp, 0, a.o_skip, a.y.b1, a.o_o1, 1, 0, it);
+        } else {
+            hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.S + RW - 1) / RW, nco), dim3(1024), lds_rv(g.L * g.Hp), st, a, a.y.wsk, g.L * g.Hp, a.y.bsk,
+                               g.S, g.L * g.Hp, a.o_hcat, a.o_skip, 1);
+            hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.O1 + RW - 1) / RW, nco), dim3(1024), lds_rv(g.Sp), st, a, a.y.w1, g.Sp, a.y.b1,
+                               g.O1, g.Sp, a.o_skip, a.o_o1, 1);
+        }
+        if (mfma && g.NO >= 32)
+            gemm(1, a.y.w2, g.O1p, g.NO, 0, g.O1p, 0, a.o_o1, a.y.b2, a.o_o2, 0, 0, it);
+        else
+            hipLaunchKernelGGL(co_rowvec_kernel, dim3((g.NO + RW - 1) / RW, nco), dim3(1024), lds_rv(g.O1p), st, a, a.y.w2, g.O1p, a.y.b2,
+                               g.NO, g.O1p, a.o_o1, a.o_o2, 0);
         if (lap) hipLaunchKernelGGL(co_tail_kernel<SWN_KIND_LAPLACE>, dim3(nco), dim3(256), 0, st, a, it);
         else hipLaunchKernelGGL(co_tail_kernel<SWN_KIND_SOFTMAX>, dim3(nco), dim3(256), 0, st, a, it);
     }
