@@ -58,6 +58,7 @@ struct ClArgs {
     int ring_off[SWN_MAXL], ring_len[SWN_MAXL];      // float ring l (l >= 1): input history of layer l (old taps)
     int mb_off[SWN_MAXL];                            // granule mailbox of layer l's OUTPUT: [seg][Hp] x {value, tag}
     int o_ms, o_m1, o_m2, stride;                    // granule vectors skip[Sp], out_1[O1p], out_2[NO]; per-utterance floats
+    int xshift;                                      // a cluster spans 2^xshift XCDs (its rows must fit the CUs' registers)
 };
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
@@ -71,8 +72,11 @@ __device__ __forceinline__ float ld1(__amdgpu_buffer_rsrc_t r, unsigned off) {  
 __device__ __forceinline__ float ld1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {         // handed-off data
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, SC1));
 }
+#ifndef SWN_GRANULE_POLICY
+#define SWN_GRANULE_POLICY SC1
+#endif
 __device__ __forceinline__ uint2 ldg_sc1(__amdgpu_buffer_rsrc_t r, unsigned off) {         // one granule {value, tag}
-    return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, SC1));
+    return __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, SWN_GRANULE_POLICY));
 }
 __device__ __forceinline__ void st1_sc1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, off, 0, SC1);
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
     // ---- cluster assembly: which XCD am I on, which slot do I get, how large did every cluster become
     unsigned xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-    xcc &= (NXCD - 1);
+    xcc = (xcc & (NXCD - 1)) >> a.xshift;                  // cluster index: 2^xshift neighbouring XCDs form one cluster
     if (tid == 0) {
         s_dead = 0;
         s_tickets[0] = aadd(a.ctrl + (CW_TICKET + xcc) * CW_STRIDE, 1u);      // my slot
@@ -235,6 +239,12 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
             const int q0 = gen ? g.rf + 1 - seg + i * seg : it;
             const int nl = gen ? L : L - 1;                  // the prologue never needs the last layer's output
             const unsigned tag = tag_base + (unsigned)it + 1u;
+            // an opaque zero, re-defined every iteration and folded into every per-lane offset below: without it the
+            // compiler hoists the address arithmetic of all six unrolled phases out of this loop (~200 registers on
+            // top of the resident rows, i.e. spills); recomputing an offset costs two or three integer instructions
+            int zi = 0;
+            asm volatile("" : "+s"(zi));
+            const int cz = c_lo + zi, ch0z = ch0 + zi, sr0z = sr0 + zi;
 
             // ---- input layer (every CU, every channel): h0 -> local ring (cswnv_shift1.py:352 / dswnv.py:345)
             for (int e = tid; e < UB * np * H; e += NT) {
@@ -263,18 +273,24 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
 
             // this wave's (<= 2) out_skip rows, lane-partial, per utterance: private LDS words of the lane
             if (gen) for (int u = 0; u < UB; ++u) { skl[((u * 4 + w) * 2 + 0) * 64 + lane] = 0.f; skl[((u * 4 + w) * 2 + 1) * 64 + lane] = 0.f; }
-            // out_skip share of hidden state h_l (l = 1..L, column block l-1), held by the lanes as x[CL]
-            auto skip_add = [&](int l, int u, const float (&x)[CL]) __attribute__((always_inline)) {
+            // out_skip share of hidden state h_l (l = 1..L, column block l-1), held by the lanes as x[CL]; the weights of
+            // this wave's two rows are fetched by skip_w ahead of the hand-off
+            auto skip_w = [&](int l, float (&wv)[2][CL]) __attribute__((always_inline)) {
 #pragma unroll
                 for (int rr = 0; rr < 2; ++rr) {
                     const int lr = w * 2 + rr;
                     const bool live = lr < nsr;
+#pragma unroll
+                    for (int c = 0; c < CL; ++c)
+                        wv[rr][c] = ld1(rP, (live && cz + c < Hp) ? (unsigned)((a.y.wsk + (size_t)(sr0z + lr) * L * Hp + (size_t)(l - 1) * Hp + cz + c) * 4) : CL_OOB);
+                }
+            };
+            auto skip_add = [&](int u, const float (&wv)[2][CL], const float (&x)[CL]) __attribute__((always_inline)) {
+#pragma unroll
+                for (int rr = 0; rr < 2; ++rr) {
                     float acc = skl[((u * 4 + w) * 2 + rr) * 64 + lane];
 #pragma unroll
-                    for (int c = 0; c < CL; ++c) {
-                        const float wv = ld1(rP, (live && c_lo + c < Hp) ? (unsigned)((a.y.wsk + (size_t)(sr0 + lr) * L * Hp + (size_t)(l - 1) * Hp + c_lo + c) * 4) : CL_OOB);
-                        acc = fmaf(wv, x[c], acc);
-                    }
+                    for (int c = 0; c < CL; ++c) acc = fmaf(wv[rr][c], x[c], acc);
                     skl[((u * 4 + w) * 2 + rr) * 64 + lane] = acc;
                 }
             };
@@ -291,8 +307,9 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                 const bool epi = tid < UB * np * nch;
                 int e_c = 0, e_j = 0, e_u = 0;
                 if (epi) {
-                    e_c = tid % nch; e_j = (tid / nch) % np; e_u = tid / (nch * np);
-                    const int o = ch0 + e_c, q = q0 + e_j, b = utt(e_u);
+                    const int tz = tid + zi;
+                    e_c = tz % nch; e_j = (tz / nch) % np; e_u = tz / (nch * np);
+                    const int o = ch0z + e_c, q = q0 + e_j, b = utt(e_u);
                     e_gz = P[a.y.bx + (size_t)l * H2 + o]; e_gc = P[a.y.bx + (size_t)l * H2 + H + o];
                     const float* condb = a.cond + (size_t)b * a.Tf * g.N;
                     for (int s = 0; s < seg; ++s) {
@@ -305,6 +322,8 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                     }
                     e_bz = P[a.y.bd + (size_t)l * H2 + o]; e_bc = P[a.y.bd + (size_t)l * H2 + H + o];
                 }
+                float wsk_r[2][CL];
+                if (gen && l >= 1) skip_w(l, wsk_r);
                 for (int u = 0; u < UB && alive; ++u) {
                     const size_t ub = (size_t)utt(u) * a.stride;
                     for (int j = 0; j < np && alive; ++j) {
@@ -318,8 +337,8 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                             const int pos = q - (K - 1 - k) * dil;
 #pragma unroll
                             for (int c = 0; c < CL; ++c) {
-                                if (l == 0) x[k][c] = c_lo + c < Hp ? ring0[(u * R0 + pmod(pos, R0)) * Hp + c_lo + c] : 0.f;
-                                else x[k][c] = ld1_sc1(rS, c_lo + c < Hp ? (unsigned)((ub + a.ring_off[l] + (size_t)pmod(pos, R) * Hp + c_lo + c) * 4) : CL_OOB);
+                                if (l == 0) x[k][c] = cz + c < Hp ? ring0[(u * R0 + pmod(pos, R0)) * Hp + cz + c] : 0.f;
+                                else x[k][c] = ld1_sc1(rS, cz + c < Hp ? (unsigned)((ub + a.ring_off[l] + (size_t)pmod(pos, R) * Hp + cz + c) * 4) : CL_OOB);
                             }
                         }
                         if (l > 0) {
@@ -329,11 +348,11 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                         if (w == 0) {
 #pragma unroll
                             for (int c = 0; c < CL; ++c) {
-                                const int o = c_lo + c - ch0;
+                                const int o = cz + c - ch0z;
                                 if (o >= 0 && o < nch) hpv[(u * SEG_MAX + j) * CPC_MAX + o] = x[KT - 1][c];
                             }
                         }
-                        if (gen && l >= 1 && j == np - 1) skip_add(l, u, x[KT - 1]);       // h_l at the step's last position
+                        if (gen && l >= 1 && j == np - 1) skip_add(u, wsk_r, x[KT - 1]);   // h_l at the step's last position
 #pragma unroll
                         for (int rw = 0; rw < RW; ++rw) {
                             float acc = 0.f;
@@ -355,7 +374,7 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
                 __syncthreads();
                 if (!alive || s_dead) { alive = false; return; }
                 if (epi) {
-                    const int o = ch0 + e_c, q = q0 + e_j;
+                    const int o = ch0z + e_c, q = q0 + e_j;
                     const size_t ub = (size_t)utt(e_u) * a.stride;
                     const float az = rsum[(e_u * SEG_MAX + e_j) * 2 * CPC_MAX + 2 * e_c] + e_bz;
                     const float ac = rsum[(e_u * SEG_MAX + e_j) * 2 * CPC_MAX + 2 * e_c + 1] + e_bc;
@@ -376,10 +395,14 @@ __global__ __launch_bounds__(NT, 1) void decode_cluster_kernel(const ClArgs a) {
             if (!gen) continue;
 
             // ---- head: out_skip (finish with h_L) -> relu -> out_1 -> relu -> out_2
-            for (int u = 0; u < UB; ++u) {
-                float x[CL];
-                if (!poll_vec((size_t)utt(u) * a.stride + a.mb_off[L - 1] + 2 * (size_t)(np - 1) * Hp, tag, x)) return;
-                skip_add(L, u, x);
+            {
+                float wsk_r[2][CL];
+                skip_w(L, wsk_r);
+                for (int u = 0; u < UB; ++u) {
+                    float x[CL];
+                    if (!poll_vec((size_t)utt(u) * a.stride + a.mb_off[L - 1] + 2 * (size_t)(np - 1) * Hp, tag, x)) return;
+                    skip_add(u, wsk_r, x);
+                }
             }
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
@@ -617,15 +640,20 @@ extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, co
     hipStream_t st = (hipStream_t)stream_;
     if (hipMemsetAsync(state, 0, sizeof(float) * (((st_floats + 63) & ~(size_t)63) + (size_t)CW_COUNT * CW_STRIDE), st) != hipSuccess)
         return SWN_E_LAUNCH;
-    // channels per lane / rows per wave for an evenly filled chip (the kernel aborts loudly if its cluster came out smaller)
+    // channels per lane; XCDs per cluster chosen so that the dil_h rows a CU owns (rows/wave x K x CL x L registers per
+    // lane) stay resident beside the ~200 registers of hoisted loop invariants: more CUs per cluster = fewer rows per CU.
+    // (The kernel aborts loudly if its cluster came out smaller than an evenly filled chip gives.)
     const int cl = (g.Hp + 63) / 64;
-    const int cpc = (g.H + grid / 8 - 1) / (grid / 8);
+    a.xshift = (g.K == 7 && cl == 3) ? 2 : ((g.K == 7 && cl == 4) ? 2 : 0);
+    const int ncu = (grid / 8) << a.xshift;                    // CUs per cluster
+    const int cpc = (g.H + ncu - 1) / ncu;
     const int rw = (2 * cpc + 3) / 4;
     if (g.seg * cpc * UBM > NT) return SWN_E_UNSUPPORTED;     // one epilogue thread per (utterance, position, own channel)
+    if ((g.S + ncu - 1) / ncu > 8) return SWN_E_UNSUPPORTED;
     rc = SWN_E_UNSUPPORTED;
     if (g.K == 3 && cl == 1 && rw <= 1) rc = launch_cluster<1, 3, 1, LL>(a, lds_req, grid, st);        // tiny fixtures (H <= 64)
-    else if (g.K == 7 && cl == 3 && rw <= 3) rc = launch_cluster<3, 7, 3, LL>(a, lds_req, grid, st);   // run.sh Laplace: rows resident
-    else if (g.K == 7 && cl == 4 && rw <= 4) rc = launch_cluster<4, 7, 4, 3>(a, lds_req, grid, st);    // run.sh softmax: rows streamed
+    else if (g.K == 7 && cl == 3 && rw <= 1) rc = launch_cluster<3, 7, 1, LL>(a, lds_req, grid, st);   // run.sh Laplace: 128 CUs, 2 channels each (experiment)
+    else if (g.K == 7 && cl == 4 && rw <= 1) rc = launch_cluster<4, 7, 1, LL>(a, lds_req, grid, st);   // run.sh softmax: 128 CUs, 2 channels each
     if (rc != SWN_OK) return rc;
     const size_t n_out = (size_t)batch * n_steps * (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg);
     hipLaunchKernelGGL(cluster_verdict_kernel, dim3(64), dim3(256), 0, st, a.ctrl, out, n_out, g.kind == SWN_KIND_SOFTMAX ? 1 : 0);

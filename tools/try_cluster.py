@@ -32,7 +32,7 @@ def fixture(name, max_steps=None):
     else:
         print("samples maxdiff %.2e heads maxdiff %.2e nan=%d" % ((a - b).abs().max().item(), (ha - hb).abs().max().item(), int(torch.isnan(b).sum())))
 
-def timing(cfg, B, Tf, variants=(3, 5)):
+def timing(cfg, B, Tf, variants=(3, 5), reps=3):
     sd = synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True)
     net = HipNet.from_state_dict(cfg, sd, "cuda:0")
     soft = cfg.kind == "softmax"
@@ -44,9 +44,12 @@ def timing(cfg, B, Tf, variants=(3, 5)):
         res = []
         for n_steps in (Tf * cfg.U // seg // 2, Tf * cfg.U // seg):
             net.decode(aux, n_steps, None, cond=cond, variant=v, rng_seed=5)
-            torch.cuda.synchronize(); t0 = time.time()
-            out, _ = net.decode(aux, n_steps, None, cond=cond, variant=v, rng_seed=5)
-            torch.cuda.synchronize(); res.append((n_steps, time.time() - t0))
+            best = 1e9
+            for _ in range(reps):
+                torch.cuda.synchronize(); t0 = time.time()
+                out, _ = net.decode(aux, n_steps, None, cond=cond, variant=v, rng_seed=5)
+                torch.cuda.synchronize(); best = min(best, time.time() - t0)
+            res.append((n_steps, best))
         outs[v] = out
         us = (res[1][1] - res[0][1]) / (res[1][0] - res[0][0]) * 1e6
         print(f"{cfg.kind} H={cfg.H} seg={seg} B={B}: variant {v}: {res[1][1]*1e3:.1f} ms for {res[1][0]} steps, steady {us:.1f} us/step", flush=True)
@@ -64,3 +67,7 @@ if __name__ == "__main__":
     elif what == "time":
         timing(C.ref6_laplace(1, 4), 1, 4); timing(C.ref6_laplace(1, 4), 8, 4); timing(C.ref6_laplace(1, 4), 64, 4)
         timing(C.ref6_laplace(5, 4), 1, 4); timing(C.ref6_softmax(), 1, 4)
+    elif what == "time1":          # single utterances, long enough for a stable slope
+        v = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (3, 5)
+        timing(C.ref6_laplace(1, 4), 1, 16, v); timing(C.ref6_laplace(5, 4), 1, 16, v); timing(C.ref6_softmax(), 1, 16, v)
+        timing(C.ref6_laplace(1, 4), 2, 16, v)
