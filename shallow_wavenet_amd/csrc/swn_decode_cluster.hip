@@ -41,6 +41,10 @@ constexpr int NXCD = 8;
 constexpr int CPC_MAX = 8;           // channels per CU (H <= 256 on >= 32 CUs)
 constexpr int SEG_MAX = 10;
 constexpr int LL = 6;                // stack depth this kernel is unrolled for
+#ifndef SWN_XS_LAP
+#define SWN_XS_LAP 0                 // XCDs per cluster (log2) at the run.sh Laplace geometry: 0, 1, 2 measured the same
+                                     // step rate (35-38 us); one XCD per cluster keeps eight utterances in flight
+#endif
 constexpr unsigned SPIN_LIMIT = 1u << 22;
 constexpr unsigned SC1 = 16;         // buffer-instruction cache policy bit: sc1
 constexpr unsigned CL_OOB = 0x80000000u;
@@ -644,7 +648,7 @@ extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, co
     // lane) stay resident beside the ~200 registers of hoisted loop invariants: more CUs per cluster = fewer rows per CU.
     // (The kernel aborts loudly if its cluster came out smaller than an evenly filled chip gives.)
     const int cl = (g.Hp + 63) / 64;
-    a.xshift = (g.K == 7 && cl == 3) ? 2 : ((g.K == 7 && cl == 4) ? 2 : 0);
+    a.xshift = (g.K == 7 && cl == 3) ? SWN_XS_LAP : ((g.K == 7 && cl == 4) ? 2 : 0);
     const int ncu = (grid / 8) << a.xshift;                    // CUs per cluster
     const int cpc = (g.H + ncu - 1) / ncu;
     const int rw = (2 * cpc + 3) / 4;
@@ -652,7 +656,9 @@ extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, co
     if ((g.S + ncu - 1) / ncu > 8) return SWN_E_UNSUPPORTED;
     rc = SWN_E_UNSUPPORTED;
     if (g.K == 3 && cl == 1 && rw <= 1) rc = launch_cluster<1, 3, 1, LL>(a, lds_req, grid, st);        // tiny fixtures (H <= 64)
-    else if (g.K == 7 && cl == 3 && rw <= 1) rc = launch_cluster<3, 7, 1, LL>(a, lds_req, grid, st);   // run.sh Laplace: 128 CUs, 2 channels each (experiment)
+    else if (g.K == 7 && cl == 3 && rw <= 1) rc = launch_cluster<3, 7, 1, LL>(a, lds_req, grid, st);   // run.sh Laplace: 128 CUs, 2 channels each
+    else if (g.K == 7 && cl == 3 && rw <= 2) rc = launch_cluster<3, 7, 2, LL>(a, lds_req, grid, st);   // 64 CUs, 3 channels each
+    else if (g.K == 7 && cl == 3 && rw <= 3) rc = launch_cluster<3, 7, 3, LL>(a, lds_req, grid, st);   // 32 CUs, 6 channels each
     else if (g.K == 7 && cl == 4 && rw <= 1) rc = launch_cluster<4, 7, 1, LL>(a, lds_req, grid, st);   // run.sh softmax: 128 CUs, 2 channels each
     if (rc != SWN_OK) return rc;
     const size_t n_out = (size_t)batch * n_steps * (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg);
