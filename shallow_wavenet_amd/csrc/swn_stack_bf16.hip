@@ -512,10 +512,13 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
 
 // ---- head: skip (K = L*64) -> relu -> out_1 (128x128) -> relu -> out_2 (<=16 x 128) ----------------
 template <int LL>
-__global__ __launch_bounds__(256, 1) void bf16_head_kernel(const BfArgs a, const int n_tiles) {
+__global__ __launch_bounds__(256, 2) void bf16_head_kernel(const BfArgs a, const int n_tiles) {
     constexpr int ROW2 = 256 + 16;               // [pos][128 ch] bf16 tile pitch
     __shared__ __attribute__((aligned(16))) unsigned char t1[TN * ROW2];
-    __shared__ __attribute__((aligned(16))) unsigned char t2[TN * ROW2];
+    // TWO workgroups per CU (65 KB of LDS and <= 256 registers each): the three GEMM stages of a tile are separated by
+    // barriers and each is a short latency chain (LDS reads -> MFMAs -> epilogue -> LDS writes), so a second workgroup's
+    // stages fill the gaps.  The out_1 tile t2 lives in the first 17 KB of the fragment buffer `bt`, which is dead once
+    // the skip GEMM has consumed it (barrier #2) and is only re-published after barrier #4.
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
     constexpr int KS1 = LL * 2;                            // K-steps of the skip GEMM
@@ -559,6 +562,8 @@ __global__ __launch_bounds__(256, 1) void bf16_head_kernel(const BfArgs a, const
     // waves read the whole tile from LDS: the tile leaves L2 once.  (One buffer is enough: a tile is published
     // after the previous tile's last barrier, when nobody reads the buffer any more.)
     extern __shared__ __attribute__((aligned(16))) unsigned char bt[];       // [4 nt][KS1][64 lanes][16 B] = 48 KB
+    unsigned char* t2 = bt;                                                  // aliases bt (see above)
+    static_assert(TN * ROW2 <= 4 * KS1 * 64 * 16, "t2 must fit inside bt");
     bf16x8 mycol[KS1];
     auto fetch_col = [&](int tix) {
         const int tc = tix < n_tiles ? tix : n_tiles - 1;
@@ -762,7 +767,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
         for (int l = 0; l < g.L; ++l)
             hipLaunchKernelGGL(bf16_layer_kernel<false>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
     }
-    const int hgrid = n_tiles < 256 ? n_tiles : 256;
+    const int hgrid = n_tiles < 512 ? n_tiles : 512;                            // two workgroups per CU
     hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 4 * 12 * 64 * 16, st, a, n_tiles);
     return swn_launch_status("swn_forward_bf16");
 }
