@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void bf16_input_kernel(const BfArgs a) {
                 float acc = cb[e + q];
                 if (has0) acc += fmaf(v0[e + q], x0, c0[e + q]);
                 acc += fmaf(v1[e + q], x1, c1[e + q]);
-                r[q] = acc / (1.f + fabsf(acc));
+                r[q] = acc * __builtin_amdgcn_rcpf(1.f + fabsf(acc));      // 1-ulp reciprocal: the result is rounded to bf16 anyway (an IEEE divide made this kernel VALU-bound)
             }
             wd[e >> 1] = (unsigned)f2bf(r[0]) | ((unsigned)f2bf(r[1]) << 16);
         }
