@@ -365,9 +365,11 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
 struct CondRow { float4 cz[4], cc[4]; };
 struct Unit { int b, f, ts, te, jj0; };        // wave-uniform: utterance, frame, [ts, te) positions, first tap index
 
+// SP > 1 cuts every frame into SP sub-units of NCH chunks (the last one shorter): with few frames per wave (BASELINE cfg4:
+// 1 200 frames over 1 024 waves) whole-frame units leave half the waves a second 7-chunk unit while the others idle.
 template <int NCH>
 __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a, const int l, const int dil,
-                                                                  const int n_units, const int Fu) {
+                                                                  const int n_units, const int Fu, const int SP) {
     __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | prescaled bx[128] of this layer
     __shared__ float wus[128];                                       // upsampler taps (U <= 112)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -412,10 +414,13 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
         Unit u;
         const bool ok = j < j1;
         const int jc = ok ? j : j1 - 1;
-        u.b = jc / Fu; u.f = jc - u.b * Fu;
+        const int fs = jc / SP, part = jc - fs * SP;                  // frame index over all utterances, sub-unit
+        u.b = fs / Fu; u.f = fs - u.b * Fu;
         const int s = u.f * a.U - a.coff, e = s + a.U;
-        u.ts = s > 0 ? s : 0;
-        u.te = ok ? (e < a.Tp ? e : a.Tp) : 0;                        // a unit past the range is empty
+        const int ps = s + part * (16 * NCH), pe = ps + 16 * NCH < e ? ps + 16 * NCH : e;
+        u.ts = ps > 0 ? ps : 0;
+        u.te = ok ? (pe < a.Tp ? pe : a.Tp) : 0;                      // a unit past the range is empty
+        if (u.te < u.ts) u.te = u.ts;
         u.jj0 = u.ts - s;
         return u;
     };
@@ -758,10 +763,14 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
         const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frame units per utterance
         const int n_units = batch * Fu;
         const int ug = (n_units + 3) / 4 < 256 ? (n_units + 3) / 4 : 256;
+        // few frames per wave: halve the units (4 + 3 chunks for U = 110) so that the waves finish together
+        const bool halves = nch > 4 && nch <= 8 && n_units < 2 * 1024;
+        const int n_half = 2 * n_units, ugh = (n_half + 3) / 4 < 256 ? (n_half + 3) / 4 : 256;
         for (int l = 0; l < g.L; ++l) {
-            if (nch <= 4) hipLaunchKernelGGL(bf16_layer_units_kernel<4>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu);
-            else if (nch == 5) hipLaunchKernelGGL(bf16_layer_units_kernel<5>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu);
-            else hipLaunchKernelGGL(bf16_layer_units_kernel<7>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu);
+            if (halves) hipLaunchKernelGGL(bf16_layer_units_kernel<4>, dim3(ugh), dim3(256), 0, st, a, l, g.dil[l], n_half, Fu, 2);
+            else if (nch <= 4) hipLaunchKernelGGL(bf16_layer_units_kernel<4>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu, 1);
+            else if (nch == 5) hipLaunchKernelGGL(bf16_layer_units_kernel<5>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu, 1);
+            else hipLaunchKernelGGL(bf16_layer_units_kernel<7>, dim3(ug), dim3(256), 0, st, a, l, g.dil[l], n_units, Fu, 1);
         }
     } else {
         for (int l = 0; l < g.L; ++l)
