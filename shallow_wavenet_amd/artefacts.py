@@ -31,6 +31,9 @@ def _numpy_safe_globals():
     except ImportError:                                     # pragma: no cover
         from numpy.core import multiarray as _ma
     out += [_ma._reconstruct, _ma.scalar]
+    # files written under numpy 1.x (the reference pins torch 1.3.1 / numpy of that era) name the same helpers by their
+    # old module path
+    out += [(_ma._reconstruct, "numpy.core.multiarray._reconstruct"), (_ma.scalar, "numpy.core.multiarray.scalar")]
     for name in ("UInt32DType", "Float64DType", "Int64DType", "Float32DType"):
         dt = getattr(getattr(np, "dtypes", None), name, None)
         if dt is not None:

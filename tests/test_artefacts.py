@@ -62,6 +62,26 @@ def test_reference_written_files_load_too(tmp_path):
         A.load_checkpoint(str(tmp_path / "bad.pkl"))
 
 
+def test_checkpoint_pickled_under_numpy_1_loads(tmp_path):
+    """a reference-era file names numpy's array reconstruction helper `numpy.core.multiarray._reconstruct` (numpy 1.x
+    module path): rewrite the pickle stream of a checkpoint to that spelling and load it."""
+    import io
+    import zipfile
+    buf = io.BytesIO()
+    torch.save({"model": {"w": torch.ones(3)}, "optimizer": {}, "numpy_random_state": np.random.get_state(),
+                "torch_random_state": torch.get_rng_state(), "iterations": 4}, buf)
+    zf = zipfile.ZipFile(io.BytesIO(buf.getvalue()))
+    pk = [n for n in zf.namelist() if n.endswith("data.pkl")][0]
+    data = zf.read(pk)
+    assert b"numpy._core.multiarray" in data
+    path = tmp_path / "checkpoint-4.pkl"
+    with zipfile.ZipFile(str(path), "w") as zo:
+        for n in zf.namelist():
+            zo.writestr(n, data.replace(b"numpy._core.multiarray", b"numpy.core.multiarray") if n == pk else zf.read(n))
+    ck = A.load_checkpoint(str(path))
+    assert ck["iterations"] == 4 and ck["numpy_random_state"][1].shape == (624,)
+
+
 def test_empty_shard_plans_no_batches():
     """fewer utterances than ranks: the spare rank decodes nothing instead of crashing in array_split."""
     from shallow_wavenet_amd import dist as D
