@@ -217,7 +217,8 @@ __global__ void bf16g_convert_kernel(const float* __restrict__ src, int ld, int 
 }
 
 // input layer: h0[b][t][o] = softsign(cb + sum_k (cv[k][o] * audio[ai - (K-1-k)] + cc[k][o]))   (Laplace; cswnv_shift1.py:203-206)
-__global__ __launch_bounds__(256) void bf16g_input_kernel(const float* __restrict__ P, size_t o_cb, size_t o_cv, size_t o_cc,
+// any kernel size (the form used for K > 8)
+__global__ __launch_bounds__(256) void bf16g_input_anyk_kernel(const float* __restrict__ P, size_t o_cb, size_t o_cv, size_t o_cc,
                                                           const float* __restrict__ audio, unsigned short* __restrict__ h0,
                                                           int H, int K, int seg, int Tp) {
     const int o = threadIdx.x, b = blockIdx.y;
@@ -232,6 +233,44 @@ __global__ __launch_bounds__(256) void bf16g_input_kernel(const float* __restric
             if (r >= 0) acc += fmaf(P[o_cv + (size_t)k * H + o], au[r], P[o_cc + (size_t)k * H + o]);
         }
         h0[((size_t)b * Tp + t) * H + o] = f2bf(acc / (1.f + fabsf(acc)));
+    }
+}
+
+constexpr int GIN_POS = 64;          // positions per workgroup of the input kernel (K <= 8)
+__global__ __launch_bounds__(256) void bf16g_input_kernel(const float* __restrict__ P, size_t o_cb, size_t o_cv, size_t o_cc,
+                                                          const float* __restrict__ audio, unsigned short* __restrict__ h0,
+                                                          int H, int K, int seg, int Tp) {
+    // thread = channel; its K fused taps (value, constant) stay in registers for the GIN_POS positions of the workgroup,
+    // the waveform window is read once into LDS (it was 2K + 1 loads per output before: 86 us at 8 x 16 500)
+    __shared__ float win[GIN_POS + 16];
+    const int o = threadIdx.x, b = blockIdx.y, t0 = blockIdx.x * GIN_POS;
+    const float* au = audio + (size_t)b * (Tp + seg - 1);
+    const int a0 = t0 + seg - 1 - (K - 1);                       // waveform index of win[0]
+    for (int e = threadIdx.x; e < GIN_POS + K - 1; e += 256) {
+        const int r = a0 + e;
+        win[e] = (r >= 0 && r < Tp + seg - 1) ? au[r] : 0.f;
+    }
+    float cvr[8], ccr[8];
+    const bool live = o < H;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        cvr[k] = (live && k < K) ? P[o_cv + (size_t)k * H + o] : 0.f;
+        ccr[k] = (live && k < K) ? P[o_cc + (size_t)k * H + o] : 0.f;
+    }
+    const float cb = live ? P[o_cb + o] : 0.f;
+    __syncthreads();
+    if (!live) return;
+    for (int i = 0; i < GIN_POS; ++i) {
+        const int t = t0 + i;
+        if (t >= Tp) break;
+        float acc = cb;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            // tap k reads waveform index ai - (K-1-k); taps before the start of the sequence are skipped (the reference's
+            // zero padding sits behind wav_conv, so neither the value nor the constant term exists there)
+            if (k < K && a0 + i + k >= 0) acc += fmaf(cvr[k], win[i + k], ccr[k]);
+        }
+        h0[((size_t)b * Tp + t) * H + o] = f2bf(acc * __builtin_amdgcn_rcpf(1.f + fabsf(acc)));
     }
 }
 
@@ -370,7 +409,9 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
     if ((size_t)g.L * lstride * 2 >= (1ull << 31) || (size_t)batch * Tp * (g.S > g.O1 ? g.S : g.O1) * 2 >= (1ull << 31)) return SWN_E_UNSUPPORTED;
     (void)hipGetLastError();
     if (g.kind == SWN_KIND_LAPLACE)
-        hipLaunchKernelGGL(bf16g_input_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
+        if (g.K <= 8) hipLaunchKernelGGL(bf16g_input_kernel, dim3((unsigned)((Tp + GIN_POS - 1) / GIN_POS), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
+                           reinterpret_cast<const float*>(audio), hs, g.H, g.K, g.seg, (int)Tp);
+        else hipLaunchKernelGGL(bf16g_input_anyk_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.cv, y.cc,
                            reinterpret_cast<const float*>(audio), hs, g.H, g.K, g.seg, (int)Tp);
     else
         hipLaunchKernelGGL(bf16g_input_softmax_kernel, dim3((unsigned)((Tp + 15) / 16), batch), dim3(256), 0, st, packed, y.cb, y.ct,
