@@ -1,0 +1,551 @@
+// Fused per-layer backward of the BL6-class stack (H=64, K=2, seg=1, Laplace) in the mixed-precision training mode:
+// the gradient side of CSWNV.forward's gated layers (cswnv_shift1.py:269-278, loss.backward() of
+// train_cswnv_laplace-stftcmplx_shift1.py:868-874), reading the bf16 time-major hidden states the bf16 forward
+// (csrc/swn_stack_bf16.hip) kept.
+//
+// The generic chain of csrc/swn_train.hip runs five launches per layer (recompute GEMM, gate, weight gradient, data
+// gradient, conditioning) that hand 2H x T fp32 tensors to each other through HBM: ~750 MB per layer at BASELINE cfg4,
+// which is what bounds it.  Here one launch per layer does everything that is local in time:
+//
+//   bl6_layer_bwd_kernel   per 16-position chunk (one wave, no barriers in the loop)
+//        dh   = E_{l+1}(t) + [Wd_{l+1}^T | Wsk_l^T] (*) [da_{l+1} ; dskip]
+//                                                          the data gradient of the layer ABOVE from the da it stored (so
+//                                                          no halo is recomputed and nothing is atomically scattered),
+//                                                          the skip path's share from dskip, and the highway carry E
+//        a    = bd + Wd_l (*) h_l                          gate pre-activations, recomputed (bf16 MFMA, as the forward)
+//        z, c, dz, dc, da = d a, dgx = d in_x-product      fp32
+//        E_l  = dh * z                                     highway carry, fp32 TIME-MAJOR [t][64] (ping-pong buffers)
+//        da_l -> bf16 time-major [t][128]                  operand of the next launch's data gradient and of the
+//                                                          weight-gradient kernel
+//        dcond[b][f][l] = sum_{t in f} w_up . dgx          work unit = one conditioning frame: plain stores
+//        g b_inx, g w_up                                   lane / LDS accumulators, a few atomics per workgroup
+//   bl6_wgrad_kernel       g Wd_l += da_l x [h_l(t-d) ; h_l(t)]^T and g bd_l for all layers in one launch: time is the
+//                          reduction axis, so both operands are staged time-major in LDS exactly as they lie in HBM
+//                          and read back transposed by ds_read_b64_tr_b16.
+// Every stream is time-major, i.e. whole 128/256-byte rows per position (a first version kept the carries in the generic
+// chain's channel-major fp32 layout: 64-byte pieces of 64 different rows per chunk, 2.5 TB/s at best).
+// Algorithmic HBM bytes per position and layer: h 128 + E_{l+1} 256 + da_{l+1} 256 + dskip 256 + E_l 256 + da_l 256
+// = 1.4 KB, plus 384 for the weight gradient, against ~5.7 KB of the generic chain (which also needs the skip path's
+// data gradient as a separate 384 x 128 GEMM and a memset of the carries).
+#include <hip/hip_runtime.h>
+#include <hip/hip_bf16.h>
+#include "swn_geom.hpp"
+
+namespace {
+
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4;
+typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8;
+
+constexpr int H = 64;
+constexpr unsigned OOB = 0x80000000u;       // host guarantees every buffer is smaller than 2 GiB
+constexpr float K_SIG = -1.44269504f;       // sigmoid(x) = 1 / (1 + 2^(K_SIG x))
+constexpr float K_TANH = 2.88539008f;       // tanh(x)    = 1 - 2 / (1 + 2^(K_TANH x))
+
+__device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_cast(unsigned short, (__bf16)x); }
+__device__ __forceinline__ unsigned pack2(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+// accumulator (tile m, lane group g, register r) <-> channel, the permutation of the forward's layer kernel: the 16
+// channels a lane finishes are the ones its own tap-1 B fragments hold, and they are two runs of 8 consecutive channels
+__device__ __host__ constexpr int chan_of(int m, int g, int r) { return 32 * (m >> 1) + 8 * g + 4 * (m & 1) + r; }
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, size_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ bf16x8 ld_bf8(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ u32x4 ld_u4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+}
+__device__ __forceinline__ float4 ld_f4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+__device__ __forceinline__ float ld_f1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
+}
+__device__ __forceinline__ void st_f1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
+}
+
+// sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane of the row
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row_sum16(float v) {
+    v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);     // row_half_mirror
+    v = dpp_add<0x140>(v);     // row_mirror
+    return v;
+}
+
+struct BwArgs {
+    const float* P; SwnLayout y;
+    const float* cond;               // (B, Tf, N)
+    const unsigned short* hs;        // [L+1][B][Tp][64] bf16: the forward's hidden states
+    float* dhs;                      // (B, (L+1)*H, Tp) fp32 channel-major: only d h_0 (rows 0..H-1) is written, for the input layer
+    float* E[2];                     // [B][Tp][64] fp32 highway carries, ping-pong: layer l writes E[l & 1], reads E[(l+1) & 1]
+    const unsigned short* dsk;       // [B][Tp][128] bf16: d relu(skip) pre-activation, time-major
+    unsigned short* da;              // [L][B][Tp][128] bf16
+    const unsigned short* wrec;      // [L][8 mt][4 ks][64 lanes][8]  Wd, rows permuted (chan_of)
+    const unsigned short* wdg;       // [L+1][4 mt][12 ks][64 lanes][8]  image c: [Wd_c^T over (tap, o2) | Wsk_{c-1}^T], rows permuted
+    float* dcond;                    // (B, Tf, N)
+    float* gP;                       // gradient of the packed parameters
+    int B, Tf, Tp, U, N, L, coff;
+    int dil[SWN_MAXL];
+};
+
+// ---- fragment images ------------------------------------------------------------------------------------------
+// recompute: A[row][k] = Wd[l][row'][k], k = tap*64 + i      (same image as the forward's pack_wd_kernel)
+__global__ void pack_wrec_kernel(const float* __restrict__ wd, int L, unsigned short* __restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= L * 8 * 4 * 512) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = (e >> 9) & 3, mt = (e >> 11) & 7, l = e >> 14;
+    const int g = (lane & 15) >> 2, r = lane & 3;
+    const int row = (mt >= 4 ? H : 0) + chan_of(mt & 3, g, r);
+    const int k = 32 * ks + 8 * (lane >> 4) + j;
+    dst[e] = f2bf(wd[((size_t)l * 128 + row) * 128 + k]);
+}
+// data gradient of consumer c (= the d h_c a layer kernel assembles), c = 0..L:
+//   k-steps 0-3: Wd_c[o2][tap 0][i] <-> da_c(t + dil_c)   4-7: Wd_c[o2][tap 1][i] <-> da_c(t)      (zero for c = L)
+//   k-steps 8-11: Wsk[s][(c-1)*64 + i] <-> dskip(t)                                                (zero for c = 0)
+__global__ void pack_wdg_kernel(const float* __restrict__ wd, const float* __restrict__ wsk, int L, unsigned short* __restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= (L + 1) * 4 * 12 * 512) return;
+    const int j = e & 7, lane = (e >> 3) & 63, rest = e >> 9, ks = rest % 12, m = (rest / 12) & 3, c = rest / 48;
+    const int rho = lane & 15, i = chan_of(m, rho >> 2, rho & 3);
+    const int kk = 32 * (ks & 3) + 8 * (lane >> 4) + j;                 // o2 or s inside the 128-wide block
+    float v = 0.f;
+    if (ks < 8) { if (c < L) v = wd[(((size_t)c * 128 + kk) * 2 + (ks >> 2)) * H + i]; }
+    else if (c >= 1) v = wsk[(size_t)kk * (L * H) + (c - 1) * H + i];
+    dst[e] = f2bf(v);
+}
+
+// d skip pre-activation, fp32 channel-major (B, 128, Tp) as the generic head backward leaves it -> bf16 time-major
+// [B][Tp][128], the B-fragment layout of the layer kernel
+__global__ __launch_bounds__(256) void dskip_tm_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int Tp,
+                                                       int tiles_per_b) {
+    __shared__ float tl[128][65];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.x / tiles_per_b, t0 = (blockIdx.x - b * tiles_per_b) * 64;
+#pragma unroll 8
+    for (int i = 0; i < 32; ++i) {
+        const int e = tid + 256 * i, ch = e >> 6, t = t0 + (e & 63);
+        tl[ch][e & 63] = t < Tp ? src[((size_t)b * 128 + ch) * Tp + t] : 0.f;
+    }
+    __syncthreads();
+    const int row = tid & 63, qu = tid >> 6, t = t0 + row;
+    if (t >= Tp) return;
+#pragma unroll
+    for (int c8 = 0; c8 < 4; ++c8) {
+        const int ch0 = (qu * 4 + c8) * 8;
+        uint4 v;
+        v.x = pack2(tl[ch0][row], tl[ch0 + 1][row]);     v.y = pack2(tl[ch0 + 2][row], tl[ch0 + 3][row]);
+        v.z = pack2(tl[ch0 + 4][row], tl[ch0 + 5][row]); v.w = pack2(tl[ch0 + 6][row], tl[ch0 + 7][row]);
+        *reinterpret_cast<uint4*>(dst + ((size_t)b * Tp + t) * 128 + ch0) = v;
+    }
+}
+
+// ---- one gated layer ----------------------------------------------------------------------------------------------
+// MODE 0: top layer l = L-1 (d h_L = skip share only)   1: inner layer   2: l = -1: only d h_0 = E_0 + Wd_0^T (*) da_0,
+// written channel-major for the input layer's backward.
+constexpr int LDS_REC = 32768;                                 // 128 x 128 bf16 fragment image (recompute)
+constexpr int LDS_DG = 49152;                                  // 64 x 384 bf16 fragment image (data gradient | skip)
+constexpr int BW_LDS = LDS_REC + LDS_DG + 4 * (256 + 128 + 128 + 128);
+constexpr int BW_THREADS = 512;                                // 8 waves, one workgroup per CU (two waves per SIMD)
+
+template <int MODE>
+__global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwArgs a, const int l, const int dil, const int dil_up,
+                                                                      const int n_units, const int Fu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* s_rec = smem;
+    unsigned char* s_dg = smem + LDS_REC;
+    float* cst = reinterpret_cast<float*>(smem + LDS_REC + LDS_DG);   // bd[128] | bx[128]
+    float* wus = cst + 256;                                    // upsampler taps [128] (U <= 112)
+    float* gwl = wus + 128;                                    // g w_up of this workgroup
+    float* gbl = gwl + 128;                                    // g bx of this workgroup
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    constexpr int KS0 = MODE == 0 ? 8 : 0, KS1 = MODE == 2 ? 8 : 12;   // k-steps of the d h GEMM this mode runs
+    {
+        const uint4* s0 = reinterpret_cast<const uint4*>(a.wrec) + (size_t)(MODE == 2 ? 0 : l) * (LDS_REC / 16);
+        const uint4* s1 = reinterpret_cast<const uint4*>(a.wdg) + (size_t)(l + 1) * (LDS_DG / 16);
+        if (MODE != 2)
+            for (int e = tid; e < LDS_REC / 16; e += BW_THREADS) reinterpret_cast<uint4*>(s_rec)[e] = s0[e];
+        for (int e = tid; e < LDS_DG / 16; e += BW_THREADS) reinterpret_cast<uint4*>(s_dg)[e] = s1[e];
+        if (MODE != 2 && tid < 256)
+            cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid] : a.P[a.y.bx + (size_t)l * 128 + tid - 128];
+        if (tid >= 256 && tid < 384) { const int i = tid - 256; wus[i] = i < a.U ? a.P[a.y.wup + i] : 0.f; gwl[i] = 0.f; gbl[i] = 0.f; }
+    }
+    __syncthreads();
+    const size_t lstride = (size_t)a.B * a.Tp * H;                       // one layer of hidden states, elements
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)(MODE == 2 ? 0 : l) * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rdu = make_rsrc(a.da + (size_t)(MODE == 0 ? 0 : l + 1) * lstride * 2, lstride * 4);
+    const __amdgpu_buffer_rsrc_t rdo = make_rsrc(a.da + (size_t)(MODE == 2 ? 0 : l) * lstride * 2, lstride * 4);
+    const __amdgpu_buffer_rsrc_t rsk = make_rsrc(a.dsk, lstride * 4);
+    const __amdgpu_buffer_rsrc_t rei = make_rsrc(a.E[(l + 1) & 1], lstride * 4);       // E_{l+1}: read
+    const __amdgpu_buffer_rsrc_t reo = make_rsrc(a.E[l & 1], lstride * 4);             // E_l: written
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
+    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_d = (unsigned)(n * 128 + 8 * g) * 2u;
+    const unsigned lane_e = (unsigned)(n * H + 8 * g) * 4u;              // fp32 [t][64]: channels 8g.. of position n
+    const unsigned dil_bytes = (unsigned)dil * H * 2u, dilu_bytes = (unsigned)dil_up * 256u;
+
+    float gbx[2][4][4];
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) gbx[q][m][r] = 0.f;
+
+    const int Wn = gridDim.x * (BW_THREADS / 64);
+    for (int j = blockIdx.x * (BW_THREADS / 64) + w; j < n_units; j += Wn) {
+        const int b = j / Fu, f = j - b * Fu;
+        const int s = f * a.U - a.coff;
+        const int ts = s > 0 ? s : 0;
+        int te = s + a.U; te = te < a.Tp ? te : a.Tp;
+        const int jj0 = ts - s;
+        float4 cz[4], cc[4];
+        if (MODE != 2) {
+            const int fc = f < a.Tf - 1 ? f : a.Tf - 1;
+            const unsigned off = (unsigned)((b * a.Tf + fc) * a.N + l * 128 + 8 * g) * 4u;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                cz[q] = ld_f4(rc, off + (unsigned)(32 * (q >> 1) + 4 * (q & 1)) * 4u);
+                cc[q] = ld_f4(rc, off + (unsigned)(H + 32 * (q >> 1) + 4 * (q & 1)) * 4u);
+            }
+        }
+        float dca[2][4][4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dca[q][m][r] = 0.f;
+
+        for (int t0 = ts; t0 < te; t0 += 16) {
+            const int t = t0 + n;
+            const bool ok = t < te;
+            const unsigned pos = (unsigned)(b * a.Tp + t0);
+            // ---- every load of the chunk is issued up front
+            f32x4 D[4];
+            if (MODE != 0) {                       // highway carry of the layer above: channels chan_of(m, g, 0..3)
+                const unsigned eo = ok ? pos * 256u + lane_e : OOB;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    D[m] = __builtin_bit_cast(f32x4, ld_u4(rei, eo + (unsigned)(32 * (m >> 1) + 4 * (m & 1)) * 4u));
+            } else {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) D[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            bf16x8 du[12];
+            {
+                const unsigned o1 = ok ? pos * 256u + lane_d : OOB;
+                if (MODE != 0) {
+                    const unsigned o0 = (ok && t + dil_up < a.Tp) ? o1 + dilu_bytes : OOB;
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) { du[ks] = ld_bf8(rdu, o0 + 64u * ks); du[4 + ks] = ld_bf8(rdu, o1 + 64u * ks); }
+                }
+                if (MODE != 2) {
+#pragma unroll
+                    for (int ks = 0; ks < 4; ++ks) du[8 + ks] = ld_bf8(rsk, o1 + 64u * ks);
+                }
+            }
+            bf16x8 x[4];
+            if (MODE != 2) {
+                const unsigned base = pos * (H * 2u) + lane_h;
+                const unsigned o1 = ok ? base : OOB;
+                const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
+                x[0] = ld_bf8(rh, o0); x[1] = ld_bf8(rh, o0 + 64u); x[2] = ld_bf8(rh, o1); x[3] = ld_bf8(rh, o1 + 64u);
+            }
+            // ---- d h_{l+1}: highway carry + data gradient of the layer above + the skip path's share
+#pragma unroll
+            for (int ks = KS0; ks < KS1; ++ks)
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(s_dg + ((m * 12 + ks) * 64 + lane) * 16);
+                    D[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, du[ks], D[m], 0, 0, 0);
+                }
+            if (MODE == 2) {                       // d h_0, channel-major (B, (L+1)*H, Tp) rows 0..63
+                const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dhs, (size_t)a.B * (a.L + 1) * H * a.Tp * 4);
+                const unsigned tp4 = (unsigned)a.Tp * 4u;
+                const unsigned eb = ok ? (unsigned)(b * (a.L + 1) * H + 8 * g) * tp4 + (unsigned)t * 4u : OOB;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_f1(rd0, eb + (unsigned)chan_of(m, 0, r) * tp4, D[m][r]);
+                continue;
+            }
+            // ---- gate pre-activations
+            f32x4 acc[8];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                acc[m] = *reinterpret_cast<const f32x4*>(cst + chan_of(m, g, 0));
+                acc[4 + m] = *reinterpret_cast<const f32x4*>(cst + H + chan_of(m, g, 0));
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 8; ++mt) {
+                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(s_rec + ((mt * 4 + ks) * 64 + lane) * 16);
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x[ks], acc[mt], 0, 0, 0);
+                }
+            // ---- gates and their derivatives (fp32)
+            const float wu = wus[jj0 + (t0 - ts) + n];
+            float pw = 0.f;
+            unsigned dav[2][8];
+            f32x4 eout[4];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const float4 bz4 = *reinterpret_cast<const float4*>(cst + 128 + chan_of(m, g, 0));
+                const float4 bc4 = *reinterpret_cast<const float4*>(cst + 128 + H + chan_of(m, g, 0));
+                const float czv[4] = {cz[m].x, cz[m].y, cz[m].z, cz[m].w}, ccv[4] = {cc[m].x, cc[m].y, cc[m].z, cc[m].w};
+                const float bzv[4] = {bz4.x, bz4.y, bz4.z, bz4.w}, bcv[4] = {bc4.x, bc4.y, bc4.z, bc4.w};
+                const u32x4 hw = __builtin_bit_cast(u32x4, x[2 + (m >> 1)]);
+                float daz[4], dac[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gz = fmaf(wu, czv[r], bzv[r]), gc = fmaf(wu, ccv[r], bcv[r]);
+                    const float az = acc[m][r], ac = acc[4 + m][r];
+                    const float z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(K_SIG * gz * az));
+                    const float q = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(K_TANH * gc * ac));
+                    const float c = fmaf(-2.f, q, 1.f);
+                    const unsigned hword = hw[(m & 1) * 2 + (r >> 1)];
+                    const float hp = __builtin_bit_cast(float, (r & 1) ? (hword & 0xffff0000u) : (hword << 16));
+                    const float dh = D[m][r];
+                    const float omz = 1.f - z;
+                    const float dz = dh * (hp - c) * z * omz;             // d / d(gz*az)
+                    const float dc = dh * omz * fmaf(-c, c, 1.f);         // d / d(gc*ac)
+                    daz[r] = dz * gz; dac[r] = dc * gc;
+                    const float gxz = dz * az, gxc = dc * ac;            // d in_x products
+                    eout[m][r] = dh * z;                                  // highway carry
+                    dca[0][m][r] = fmaf(wu, gxz, dca[0][m][r]); dca[1][m][r] = fmaf(wu, gxc, dca[1][m][r]);
+                    gbx[0][m][r] += gxz; gbx[1][m][r] += gxc;
+                    pw = fmaf(gxz, czv[r], pw); pw = fmaf(gxc, ccv[r], pw);
+                }
+                dav[0][m * 2] = pack2(daz[0], daz[1]); dav[0][m * 2 + 1] = pack2(daz[2], daz[3]);
+                dav[1][m * 2] = pack2(dac[0], dac[1]); dav[1][m * 2 + 1] = pack2(dac[2], dac[3]);
+            }
+            // ---- stores: da (bf16, [t][128]) and E_l (fp32, [t][64])
+            {
+                const unsigned so = ok ? pos * 256u + lane_d : OOB;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int hlf = 0; hlf < 2; ++hlf) {
+                        const u32x4 v = {dav[q][4 * hlf], dav[q][4 * hlf + 1], dav[q][4 * hlf + 2], dav[q][4 * hlf + 3]};
+                        __builtin_amdgcn_raw_buffer_store_b128(v, rdo, so + 128u * q + 64u * hlf, 0, 0);
+                    }
+                const unsigned eo = ok ? pos * 256u + lane_e : OOB;
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, eout[m]), reo,
+                                                           eo + (unsigned)(32 * (m >> 1) + 4 * (m & 1)) * 4u, 0, 0);
+            }
+            // g w_up[jj] += sum_o2 dgx[o2][t] * cond[f][o2]: finish the sum over the four lane groups
+            pw += __shfl_xor(pw, 16);
+            pw += __shfl_xor(pw, 32);
+            if (g == 0 && ok) atomicAdd(gwl + jj0 + (t0 - ts) + n, pw);
+        }
+        if (MODE != 2) {
+            // dcond[b][f][l*128 + o2] = sum over the frame's positions
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) dca[q][m][r] = row_sum16(dca[q][m][r]);
+            if (n == 0) {
+                float* dst = a.dcond + ((size_t)b * a.Tf + f) * a.N + (size_t)l * 128;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+                        *reinterpret_cast<float4*>(dst + q * H + chan_of(m, g, 0)) =
+                            make_float4(dca[q][m][0], dca[q][m][1], dca[q][m][2], dca[q][m][3]);
+            }
+        }
+    }
+    if (MODE == 2) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float v = row_sum16(gbx[q][m][r]);
+                if (n == 0) atomicAdd(gbl + q * H + chan_of(m, g, r), v);
+            }
+    __syncthreads();
+    if (tid < 128) atomicAdd(a.gP + a.y.bx + (size_t)l * 128 + tid, gbl[tid]);
+    else if (tid - 128 < a.U) atomicAdd(a.gP + a.y.wup + tid - 128, gwl[tid - 128]);
+}
+
+// ---- weight gradient of the dilated convs, all layers in one launch --------------------------------------------------
+// g Wd_l[o2][k] += sum_t da_l[o2][t] * X_l[k][t],  X_l(t) = [h_l(t - d_l) ; h_l(t)],  g bd_l[o2] += sum_t da_l[o2][t].
+// Workgroup = (time split, layer); per step a 32-position tile of both operands is staged in LDS in the layout it has in
+// HBM ([t][128] bf16, 16-byte chunks XOR-swizzled against bank conflicts) and the MFMA fragments - which want the
+// reduction axis t inside a lane - are read with the transposing ds_read_b64_tr_b16.  Wave w owns rows 32w..32w+31 of the
+// 128 x 128 result (16 accumulator tiles); bd comes from an all-ones B fragment.
+__device__ __forceinline__ unsigned tile_off(int row, int ch) { return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
+
+__global__ __launch_bounds__(256) void bl6_wgrad_kernel(const BwArgs a, const int tiles_per_b, const int n_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char img[2][2][32 * 256];     // [buffer][da | x][32 rows x 256 B]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int n = lane & 15, g = lane >> 4;
+    const int l = blockIdx.y, dil = a.dil[l];
+    const size_t lstride = (size_t)a.B * a.Tp * H;
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.da + (size_t)l * lstride * 2, lstride * 4);
+    const int lrow = tid >> 4, lch = tid & 15;
+    u32x4 vd[2], vx[2];
+    auto fetch = [&](int tix) {
+        const bool tok = tix < n_tiles;
+        const int tc = tok ? tix : n_tiles - 1;
+        const int b = tc / tiles_per_b, t0 = (tc - b * tiles_per_b) * 32;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int t = t0 + lrow + 16 * i;
+            const bool ok = tok && t < a.Tp;
+            vd[i] = ld_u4(rd, ok ? (unsigned)((b * a.Tp + t) * 128 + 8 * lch) * 2u : OOB);
+            const int tt = lch < 8 ? t - dil : t;
+            vx[i] = ld_u4(rh, (ok && tt >= 0) ? (unsigned)((b * a.Tp + tt) * H + 8 * (lch & 7)) * 2u : OOB);
+        }
+    };
+    f32x4 acc[2][8], accb[2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        accb[mi] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[mi][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    // transposed-read addresses: lane 4q+p of group kg supplies row 8kg + 4h + q, 16-byte chunk 2*tile + (p>>1), half p&1
+    const int q = n >> 2, p = n & 3;
+    unsigned roff[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) roff[h] = (unsigned)(8 * g + 4 * h + q);
+    fetch(blockIdx.x);
+    int cur = 0;
+    for (int tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned o = tile_off(lrow + 16 * i, lch);
+            *reinterpret_cast<u32x4*>(&img[cur][0][o]) = vd[i];
+            *reinterpret_cast<u32x4*>(&img[cur][1][o]) = vx[i];
+        }
+        fetch(tix + gridDim.x);
+        __syncthreads();
+        auto frag = [&](const unsigned char* im, int tile) -> bf16x8 {
+            s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(im + tile_off((int)roff[0], 2 * tile + (p >> 1)) + 8 * (p & 1)));
+            s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+                (__attribute__((address_space(3))) s16x4*)(im + tile_off((int)roff[1], 2 * tile + (p >> 1)) + 8 * (p & 1)));
+            const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            return __builtin_bit_cast(bf16x8, v);
+        };
+        bf16x8 af[2];
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            af[mi] = frag(&img[cur][0][0], 2 * w + mi);
+            accb[mi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], __builtin_bit_cast(bf16x8, ones), accb[mi], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const bf16x8 bfr = frag(&img[cur][1][0], nt);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) acc[mi][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[mi], bfr, acc[mi][nt], 0, 0, 0);
+        }
+        cur ^= 1;
+    }
+    float* gw = a.gP + a.y.wd + (size_t)l * 128 * 128;
+    float* gb = a.gP + a.y.bd + (size_t)l * 128;
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * (2 * w + mi) + 4 * g + r;
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) atomicAdd(gw + (size_t)row * 128 + 16 * nt + n, acc[mi][nt][r]);
+            if (n == 0) atomicAdd(gb + row, accb[mi][r]);
+        }
+}
+
+template <int MODE>
+int launch_layer(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, int grid, hipStream_t st) {
+    auto kern = bl6_layer_bwd_kernel<MODE>;
+    static bool attr_done = false;                                // per instantiation; the attribute is per function
+    if (!attr_done) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS) != hipSuccess)
+            return SWN_E_LAUNCH;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BW_THREADS), BW_LDS, st, a, l, dil, dil_up, n_units, Fu);
+    return SWN_OK;
+}
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+}  // namespace
+
+// ---- interface to csrc/swn_train.hip ------------------------------------------------------------------------------------
+bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames) {
+    if (!g.bl6 || g.kind != SWN_KIND_LAPLACE || g.seg != 1 || g.Hp != g.H || g.S != 128 || g.U < 16 || g.U > 112) return false;
+    // 32-bit buffer offsets
+    if ((size_t)B * (g.L + 1) * g.H * Tp * 4 >= (1ull << 31) || (size_t)B * Tp * 256 >= (1ull << 31) ||
+        (size_t)B * n_frames * g.N * 4 >= (1ull << 31)) return false;
+    return true;
+}
+
+size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp) {
+    const size_t row = al256((size_t)B * Tp * 256);              // one [B][Tp][128] bf16 or [B][Tp][64] fp32 buffer
+    return al256((size_t)g.L * LDS_REC) + al256((size_t)(g.L + 1) * LDS_DG) + (size_t)(g.L + 3) * row;
+}
+
+// after the head's backward has left d skip (fp32, (B, S, Tp)): the gated layers.  Leaves d h_0 in dhs rows 0..H-1 of every
+// utterance (nothing else of dhs is touched), dcond, and the wd / bd / bx / wup sections of gpacked.
+int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const void* hs_bf16,
+                       const float* dskip, float* dhs, float* dcond, float* gpacked, void* scratch, int B, int n_frames, long Tp,
+                       hipStream_t st) {
+    BwArgs a;
+    a.P = packed; a.y = y; a.cond = cond; a.hs = reinterpret_cast<const unsigned short*>(hs_bf16); a.dhs = dhs;
+    unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
+    const size_t row = al256((size_t)B * Tp * 256);
+    unsigned short* wrec = reinterpret_cast<unsigned short*>(p); p += al256((size_t)g.L * LDS_REC);
+    unsigned short* wdg = reinterpret_cast<unsigned short*>(p);  p += al256((size_t)(g.L + 1) * LDS_DG);
+    a.E[0] = reinterpret_cast<float*>(p); p += row;
+    a.E[1] = reinterpret_cast<float*>(p); p += row;
+    unsigned short* dsk = reinterpret_cast<unsigned short*>(p); p += row;
+    a.dsk = dsk;
+    a.da = reinterpret_cast<unsigned short*>(p);                 // L buffers of B*Tp*256 bytes, contiguous (no padding)
+    a.wrec = wrec; a.wdg = wdg;
+    a.dcond = dcond; a.gP = gpacked;
+    a.B = B; a.Tf = n_frames; a.Tp = (int)Tp; a.U = g.U; a.N = g.N; a.L = g.L; a.coff = g.seg;
+    for (int l = 0; l < SWN_MAXL; ++l) a.dil[l] = l < g.L ? g.dil[l] : 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(pack_wrec_kernel, dim3((g.L * 8 * 4 * 512 + 255) / 256), dim3(256), 0, st, packed + y.wd, g.L, wrec);
+    hipLaunchKernelGGL(pack_wdg_kernel, dim3(((g.L + 1) * 4 * 12 * 512 + 255) / 256), dim3(256), 0, st, packed + y.wd,
+                       packed + y.wsk, g.L, wdg);
+    const int tiles64 = (int)((Tp + 63) / 64);
+    hipLaunchKernelGGL(dskip_tm_kernel, dim3((unsigned)(B * tiles64)), dim3(256), 0, st, dskip, dsk, (int)Tp, tiles64);
+    const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;               // frame units per utterance
+    const int n_units = B * Fu;
+    const int wpw = BW_THREADS / 64;
+    const int grid = (n_units + wpw - 1) / wpw < 256 ? (n_units + wpw - 1) / wpw : 256;   // one workgroup per CU
+    int rc = SWN_OK;
+    for (int l = g.L - 1; l >= 0 && rc == SWN_OK; --l) {
+        if (l == g.L - 1) rc = launch_layer<0>(a, l, g.dil[l], 1, n_units, Fu, grid, st);
+        else rc = launch_layer<1>(a, l, g.dil[l], g.dil[l + 1], n_units, Fu, grid, st);
+    }
+    if (rc == SWN_OK) rc = launch_layer<2>(a, -1, 1, g.dil[0], n_units, Fu, grid, st);
+    if (rc != SWN_OK) return rc;
+    const int tiles_per_b = (int)((Tp + 31) / 32), n_tiles = B * tiles_per_b;
+    const int split = n_tiles < 128 ? n_tiles : 128;
+    hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split, g.L), dim3(256), 0, st, a, tiles_per_b, n_tiles);
+    return swn_launch_status("swn_backward_bf16");
+}

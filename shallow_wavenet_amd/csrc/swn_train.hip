@@ -985,13 +985,22 @@ int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* pac
     return SWN_OK;
 }
 
+// fused per-layer backward of the BL6 class in the mixed-precision mode (csrc/swn_bwd_bl6.hip)
+bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames);
+size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp);
+int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const void* hs_bf16,
+                       const float* dskip, float* dhs, float* dcond, float* gpacked, void* scratch, int B, int n_frames, long Tp,
+                       hipStream_t st);
+
 namespace {
 
+// hs_bf16 != null: the gated layers run through swn_bl6_bwd_layers (the caller has checked swn_bl6_bwd_supported and
+// appended swn_bl6_bwd_scratch_bytes to `work`)
 int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
                   const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
                   const float* drop_x, const float* const* drop_h,
                   const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_,
-                  const char* where) {
+                  const char* where, const void* hs_bf16 = nullptr) {
     GateBwd ga;
     int rc = swn_make_geom(d, &ga.g);
     if (rc < 0) return rc;
@@ -1039,7 +1048,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const float* gx = xm + r64((size_t)B * g.A0 * Tx);
     float* dxm = dfe + r64(fe_tot * B * n_frames);
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
-    if (hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
+    // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
+    if (!hs_bf16 && hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     const long hsb = (long)(L + 1) * H * Tp;
 
     // ---- head: out_2, out_1, skip
@@ -1062,17 +1072,22 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     {   // dh_l (skip part) = Wsk_l^T dskip for all l at once ; gWsk += dskip hcat^T
         TimeGemm t = {packed + y.wsk, 1, 0, (long)L * g.Hp, dskip, (long)S * Tp, Tp, 1, dhs + (size_t)H * Tp, hsb, Tp, nullptr, 0, 0,
                       L * H, 1, S, Tp, 1, 0, 1, 0};
-        launch_time(t, B, st);
+        if (!hs_bf16) launch_time(t, B, st);            // fused layer path: folded into the layer kernels' d h GEMM
         ReduceGemm r = {dskip, (long)S * Tp, Tp, 1, hs + (size_t)H * Tp, hsb, Tp, 1, gpacked + y.wsk, (long)L * g.Hp, 0, 1, gpacked + y.bsk,
                         S, 1, L * H, Tp, 1, 0, 1, 0};
         launch_reduce(r, B, st);
     }
-    // ---- layers, last to first
     ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx;
     ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
     ga.gx = drop ? gx : nullptr;
     ga.gwxa = g.audio_in ? gpacked + y.wxa : nullptr;
-    for (int l = L - 1; l >= 0; --l) {
+    // ---- layers, last to first
+    if (hs_bf16) {
+        if (drop || !swn_bl6_bwd_supported(g, B, Tp, n_frames)) return SWN_E_UNSUPPORTED;
+        const int rcl = swn_bl6_bwd_layers(g, y, packed, cond, hs_bf16, dskip, dhs, dcond, gpacked, dxm, B, n_frames, Tp, st);
+        if (rcl < 0) return rcl;
+    }
+    for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
         ga.l = l;
         // dropout mode: this layer's input is h_{l-1} times the mask drawn for layer l-1's output (cswnv_shift1.py:269-273)
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;
@@ -1176,6 +1191,25 @@ extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const fl
                             const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
     return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, hs_opt, nullptr, nullptr, grad_out, batch, n_frames,
                          work, gpacked, stream_, "swn_backward");
+}
+
+// mixed-precision backward of the BL6 class with the gated layers fused per layer: work_bf16_dev is the work buffer
+// swn_forward_bf16 filled (bf16 time-major hidden states), fwd_work_dev its fp32 expansion (swn_bf16_work_to_f32).
+extern "C" size_t swn_backward_bf16_work_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
+    const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
+    if (g.kind != SWN_KIND_LAPLACE || Tp < 1 || !swn_bl6_bwd_supported(g, batch, Tp, n_frames)) return 0;
+    const size_t base = swn_backward_work_floats(d, batch, n_frames);
+    return base ? base + r64((swn_bl6_bwd_scratch_bytes(g, batch, Tp) + 3) / 4) : 0;
+}
+
+extern "C" int swn_backward_bf16(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
+                                 const float* fe_work, const void* audio, const float* fwd_work, const void* work_bf16,
+                                 const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
+    if (!work_bf16) return SWN_E_BADARG;
+    if (swn_backward_bf16_work_floats(d, batch, n_frames) == 0) return SWN_E_UNSUPPORTED;
+    return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, nullptr, nullptr, nullptr, grad_out, batch, n_frames,
+                         work, gpacked, stream_, "swn_backward_bf16", work_bf16);
 }
 
 extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames) {

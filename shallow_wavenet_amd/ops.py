@@ -346,5 +346,38 @@ def _(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc):
     return torch.empty_like(packed)
 
 
+@custom_op("swn::stack_backward_bf16", mutates_args=())
+def stack_backward_bf16(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
+                        audio: torch.Tensor, fwd_work: torch.Tensor, work_bf16: torch.Tensor, grad_raw: torch.Tensor,
+                        desc: List[int]) -> torch.Tensor:
+    """stack_backward after a bf16 forward of the BL6 class, gated layers fused per layer (swn_backward_bf16); raises
+    where swn_backward_bf16_work_floats() is 0 (callers check `backward_bf16_supported` first)."""
+    Lb = _lib.lib()
+    d = _desc(desc)
+    dev = packed.device
+    B, Tf = cond.shape[0], cond.shape[1]
+    r = ctypes.byref(d)
+    n = Lb.swn_backward_bf16_work_floats(r, B, Tf)
+    if n == 0:
+        raise RuntimeError("swn_backward_bf16 does not cover this geometry / size")
+    grad_raw = grad_raw.to(dev, torch.float32).contiguous()
+    work = torch.empty(n, dtype=torch.float32, device=dev)
+    gp = torch.empty_like(packed)
+    with torch.cuda.device(dev):
+        _lib.check(Lb.swn_backward_bf16(r, _ptr(packed), _ptr(aux), _ptr(cond), _ptr(fe_work), _ptr(audio), _ptr(fwd_work),
+                                        _ptr(work_bf16), _ptr(grad_raw), B, Tf, _ptr(work), _ptr(gp), _stream(dev)),
+                   "backward_bf16")
+    return gp
+
+
+@stack_backward_bf16.register_fake
+def _(packed, aux, cond, fe_work, audio, fwd_work, work_bf16, grad_raw, desc):
+    return torch.empty_like(packed)
+
+
+def backward_bf16_supported(desc: List[int], batch: int, n_frames: int) -> bool:
+    return _lib.lib().swn_backward_bf16_work_floats(ctypes.byref(_desc(desc)), batch, n_frames) > 0
+
+
 OP_NAMES = ("pack_params", "frontend", "decode", "stack_forward", "pack_bf16", "stack_forward_bf16", "laplace_head",
-            "laplace_head_backward", "stack_backward")
+            "laplace_head_backward", "stack_backward", "stack_backward_bf16")

@@ -135,6 +135,7 @@ class HipNet:
         self.lib = _lib.lib()
         self.packed = packed.to(self.device, non_blocking=False).contiguous()
         self.packed_version = 0          # bumped by repack(): derived copies (bf16 weights) follow it
+        self.fused_backward = True       # mixed-precision mode, BL6 class: swn_backward_bf16 (False: the generic chain)
 
     def repack(self, tensors: Sequence[torch.Tensor]) -> None:
         """refresh the packed buffer IN PLACE from the live parameter tensors on the device (after an optimizer
@@ -222,9 +223,10 @@ class HipNet:
         if self.lib.swn_train_get_precision() == 1:
             d = ctypes.byref(self.desc)
             work = torch.empty(self.lib.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-            out = self._bf16_train_forward(cond, audio, B, Tf, work)
-            if out is not None:
-                return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
+            res = self._bf16_train_forward(cond, audio, B, Tf, work)
+            if res is not None:
+                out, wb = res
+                return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, work_bf16=wb, B=B, Tf=Tf)
         out, work, _ = _O.stack_forward(self.packed, cond, audio, self.dlist, False)
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
 
@@ -251,7 +253,7 @@ class HipNet:
             _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
                                           _ptr(wb), _ptr(out), st), "forward_bf16")
             _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), st), "bf16_work_to_f32")
-        return out
+        return out, wb
 
     def _drop_args(self, drop):
         drop_x, drop_h = drop
@@ -302,6 +304,12 @@ class HipNet:
                                                ctypes.cast(ptrs, ctypes.c_void_p), _ptr(grad_raw), B, Tf, _ptr(work),
                                                _ptr(gp), _stream_ptr(self.device)), "backward_drop")
             return gp
+        wb = saved.get("work_bf16")
+        if (wb is not None and self.fused_backward and L.swn_train_get_precision() == 1
+                and _ops.backward_bf16_supported(self.dlist, B, Tf)):
+            # BL6 class after a bf16 forward: the gated layers' backward fused per layer (csrc/swn_bwd_bl6.hip)
+            return _O.stack_backward_bf16(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
+                                          saved["work"], wb, grad_raw, self.dlist)
         return _O.stack_backward(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
                                  saved["work"], grad_raw, self.dlist)
 

@@ -1,0 +1,85 @@
+"""GPU: the fused per-layer backward of the BL6 class (swn_backward_bf16, csrc/swn_bwd_bl6.hip) against the generic chain
+of csrc/swn_train.hip in the same mixed-precision mode, on the packed-gradient buffer.
+
+Both round the same operands to bf16 (the hidden states are bf16 to begin with, da is rounded where it enters the
+matrix cores), so what differs is the summation order and the transcendental unit (exp2/rcp against expf/tanhf):
+per packed section ||g_fused - g_chain|| <= 1e-2 ||g_chain|| (measured ~1e-3).  The fp32 mode of the generic chain is the
+looser yardstick of tests/test_gpu_train_bf16.py (5e-2), which now runs through the fused path too."""
+import numpy as np
+import pytest
+import torch
+
+from shallow_wavenet_amd import config as C
+from shallow_wavenet_amd.runtime import HipNet, layout_offsets, train_precision
+from shallow_wavenet_amd.synth import synth_aux, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+
+
+def _sections(cfg, gp):
+    y = layout_offsets(cfg)
+    names = sorted((k for k in y if k != "total"), key=lambda k: y[k])
+    offs = [y[k] for k in names] + [y["total"]]
+    out = {}
+    for i, k in enumerate(names):
+        if offs[i + 1] > offs[i]:
+            out[k] = gp[offs[i]:offs[i + 1]].double().cpu().numpy()
+    return out
+
+
+def _run(cfg, B, Tf, seed=5):
+    net = HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True), "cuda:0")
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    T = Tf * cfg.U
+    g = torch.Generator().manual_seed(seed)
+    audio = (torch.rand(B, 1, T - cfg.seg, generator=g) * 1.8 - 0.9).cuda()
+    Tp = T - 2 * cfg.seg + 1
+    grad_raw = (torch.randn(B, cfg.n_out, Tp, generator=g) / Tp).cuda()
+    with train_precision("bf16"):
+        raw, saved = net.forward_train(aux, audio)
+        assert saved.get("work_bf16") is not None, "bf16 forward did not engage"
+        net.fused_backward = True
+        g1 = net.backward(saved, grad_raw)
+        net.fused_backward = False
+        g0 = net.backward(saved, grad_raw)
+    torch.cuda.synchronize()
+    assert not torch.equal(g1, g0), "the fused path did not engage"
+    return net, g1, g0
+
+
+@pytest.mark.parametrize("lpc", [0, 2])
+@pytest.mark.parametrize("B,Tf", [(1, 2), (3, 12), (2, 33)])
+def test_fused_layers_match_the_chain(gpu_ok, B, Tf, lpc):
+    cfg = C.bl6_laplace(1, lpc)
+    net, g1, g0 = _run(cfg, B, Tf)
+    from shallow_wavenet_amd import ops
+    assert ops.backward_bf16_supported(net.dlist, B, Tf)
+    assert torch.isfinite(g1).all() and torch.isfinite(g0).all()
+    s1, s0 = _sections(cfg, g1), _sections(cfg, g0)
+    big = max(np.linalg.norm(v) for v in s0.values())
+    for k, r in s0.items():
+        nr = np.linalg.norm(r)
+        if nr == 0.0:
+            assert np.linalg.norm(s1[k]) == 0.0, k
+            continue
+        err = np.linalg.norm(s1[k] - r)
+        assert err <= 1e-2 * nr + 1e-4 * big, (k, err, nr)
+
+
+def test_fused_backward_other_upsampling(gpu_ok):
+    """U = 80 (5 chunks per frame, none ragged) and U = 37 (3 chunks, ragged)."""
+    import dataclasses
+    for U in (80, 37):
+        cfg = dataclasses.replace(C.bl6_laplace(1, 0), upsampling_factor=U)
+        net, g1, g0 = _run(cfg, 2, 7)
+        s1, s0 = _sections(cfg, g1), _sections(cfg, g0)
+        big = max(np.linalg.norm(v) for v in s0.values())
+        for k, r in s0.items():
+            err = np.linalg.norm(s1[k] - r)
+            assert err <= 1e-2 * np.linalg.norm(r) + 1e-4 * big, (U, k, err)
+
+
+def test_unsupported_geometries_report_zero(gpu_ok):
+    from shallow_wavenet_amd import ops
+    for cfg in (C.bl6_laplace(2, 0), C.ref6_laplace(1, 4), C.bl6_softmax()):
+        assert not ops.backward_bf16_supported(ops.desc_list(cfg), 2, 8)

@@ -13,6 +13,7 @@ MODE = sys.argv[3] if len(sys.argv) > 3 else "fp32"
 train_precision(MODE)
 ONLY = sys.argv[4].upper() if len(sys.argv) > 4 else None      # optional 4th argument: bl6 | ref6
 WITH_OPT = len(sys.argv) > 5 and sys.argv[5] == "opt"           # optional 5th argument "opt": Adam step inside the loop
+CHAIN = len(sys.argv) > 6 and sys.argv[6] == "chain"            # optional 6th argument "chain": generic per-layer backward
 for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     if ONLY and nm != ONLY:
         continue
@@ -30,6 +31,8 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
 
     def step():
+        if CHAIN:
+            m._engine().fused_backward = False
         res = m(aux, audio)
         mu, b, log_b = res[0].reshape(B, Tp), res[1].reshape(B, Tp), res[2].reshape(B, Tp)
         loss = mc.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
@@ -49,4 +52,4 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     macs_fwd = (cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.S * cfg.S + cfg.n_out * cfg.S) * B * Tp
-    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
+    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}{' chain' if CHAIN else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
