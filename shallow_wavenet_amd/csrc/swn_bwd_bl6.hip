@@ -86,8 +86,8 @@ __device__ __forceinline__ float row_sum16(float v) {
 struct BwArgs {
     const float* P; SwnLayout y;
     const float* cond;               // (B, Tf, N)
+    const float* audio;              // (B, Tp) waveform input of the causal layer (seg == 1)
     const unsigned short* hs;        // [L+1][B][Tp][64] bf16: the forward's hidden states
-    float* dhs;                      // (B, (L+1)*H, Tp) fp32 channel-major: only d h_0 (rows 0..H-1) is written, for the input layer
     float* E[2];                     // [B][Tp][64] fp32 highway carries, ping-pong: layer l writes E[l & 1], reads E[(l+1) & 1]
     const unsigned short* dsk;       // [B][Tp][128] bf16: d relu(skip) pre-activation, time-major
     unsigned short* da;              // [L][B][Tp][128] bf16
@@ -151,8 +151,9 @@ __global__ __launch_bounds__(256) void dskip_tm_kernel(const float* __restrict__
 }
 
 // ---- one gated layer ----------------------------------------------------------------------------------------------
-// MODE 0: top layer l = L-1 (d h_L = skip share only)   1: inner layer   2: l = -1: only d h_0 = E_0 + Wd_0^T (*) da_0,
-// written channel-major for the input layer's backward.
+// MODE 0: top layer l = L-1 (d h_L = skip share only)   1: inner layer   2: l = -1: d h_0 = E_0 + Wd_0^T (*) da_0 and,
+// straight from the accumulators, the input layer's backward (h_0 = softsign(cb + lifted causal taps), cswnv_shift1.py:
+// 201-209 as packed: g cb, g cv, g cc) - d h_0 never goes to memory.
 constexpr int LDS_REC = 32768;                                 // 128 x 128 bf16 fragment image (recompute)
 constexpr int LDS_DG = 49152;                                  // 64 x 384 bf16 fragment image (data gradient | skip)
 constexpr int BW_LDS = LDS_REC + LDS_DG + 4 * (256 + 128 + 128 + 128);
@@ -180,7 +181,9 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
         for (int e = tid; e < LDS_DG / 16; e += BW_THREADS) reinterpret_cast<uint4*>(s_dg)[e] = s1[e];
         if (MODE != 2 && tid < 256)
             cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid] : a.P[a.y.bx + (size_t)l * 128 + tid - 128];
-        if (tid >= 256 && tid < 384) { const int i = tid - 256; wus[i] = i < a.U ? a.P[a.y.wup + i] : 0.f; gwl[i] = 0.f; gbl[i] = 0.f; }
+        if (MODE == 2 && tid < 320)                // cb | cv tap 0 | cv tap 1 | cc tap 0 | cc tap 1  (overlays wus, unused here)
+            cst[tid] = tid < 64 ? a.P[a.y.cb + tid] : tid < 192 ? a.P[a.y.cv + tid - 64] : a.P[a.y.cc + tid - 192];
+        if (tid >= 384) { const int i = tid - 384; if (MODE != 2) wus[i] = i < a.U ? a.P[a.y.wup + i] : 0.f; gwl[i] = 0.f; gbl[i] = 0.f; }
     }
     __syncthreads();
     const size_t lstride = (size_t)a.B * a.Tp * H;                       // one layer of hidden states, elements
@@ -191,6 +194,7 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
     const __amdgpu_buffer_rsrc_t rei = make_rsrc(a.E[(l + 1) & 1], lstride * 4);       // E_{l+1}: read
     const __amdgpu_buffer_rsrc_t reo = make_rsrc(a.E[l & 1], lstride * 4);             // E_l: written
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
+    const __amdgpu_buffer_rsrc_t rau = make_rsrc(a.audio, (size_t)a.B * a.Tp * 4);
     const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_d = (unsigned)(n * 128 + 8 * g) * 2u;
     const unsigned lane_e = (unsigned)(n * H + 8 * g) * 4u;              // fp32 [t][64]: channels 8g.. of position n
     const unsigned dil_bytes = (unsigned)dil * H * 2u, dilu_bytes = (unsigned)dil_up * 256u;
@@ -202,6 +206,13 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
         for (int m = 0; m < 4; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gbx[q][m][r] = 0.f;
+    float inl[4][4][4];                            // MODE 2: g cb | g cv tap 0 | g cv tap 1 | g cc tap 0 of this lane's channels
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) inl[q][m][r] = 0.f;
 
     const int Wn = gridDim.x * (BW_THREADS / 64);
     for (int j = blockIdx.x * (BW_THREADS / 64) + w; j < n_units; j += Wn) {
@@ -257,6 +268,11 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
                 }
             }
             bf16x8 x[4];
+            float au0 = 0.f, au1 = 0.f;
+            if (MODE == 2) {
+                au1 = ld_f1(rau, ok ? (pos + n) * 4u : OOB);
+                au0 = ld_f1(rau, (ok && t >= 1) ? (pos + n - 1) * 4u : OOB);
+            }
             if (MODE != 2) {
                 const unsigned base = pos * (H * 2u) + lane_h;
                 const unsigned o1 = ok ? base : OOB;
@@ -271,14 +287,25 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
                     const bf16x8 af = *reinterpret_cast<const bf16x8*>(s_dg + ((m * 12 + ks) * 64 + lane) * 16);
                     D[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, du[ks], D[m], 0, 0, 0);
                 }
-            if (MODE == 2) {                       // d h_0, channel-major (B, (L+1)*H, Tp) rows 0..63
-                const __amdgpu_buffer_rsrc_t rd0 = make_rsrc(a.dhs, (size_t)a.B * (a.L + 1) * H * a.Tp * 4);
-                const unsigned tp4 = (unsigned)a.Tp * 4u;
-                const unsigned eb = ok ? (unsigned)(b * (a.L + 1) * H + 8 * g) * tp4 + (unsigned)t * 4u : OOB;
+            if (MODE == 2) {                       // input layer: h_0 = softsign(pre), pre = cb + [t >= 1](cv0 x(t-1) + cc0) + cv1 x(t) + cc1
+                const float m0 = t >= 1 ? 1.f : 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < 4; ++m) {
+                    const int ch = chan_of(m, g, 0);
+                    const f32x4 kb = *reinterpret_cast<const f32x4*>(cst + ch), v0 = *reinterpret_cast<const f32x4*>(cst + 64 + ch),
+                                v1 = *reinterpret_cast<const f32x4*>(cst + 128 + ch), c0 = *reinterpret_cast<const f32x4*>(cst + 192 + ch),
+                                c1 = *reinterpret_cast<const f32x4*>(cst + 256 + ch);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) st_f1(rd0, eb + (unsigned)chan_of(m, 0, r) * tp4, D[m][r]);
+                    for (int r = 0; r < 4; ++r) {
+                        const float pre = kb[r] + m0 * fmaf(v0[r], au0, c0[r]) + fmaf(v1[r], au1, c1[r]);
+                        const float rd = __builtin_amdgcn_rcpf(1.f + fabsf(pre));
+                        const float d = D[m][r] * rd * rd;                 // a position past the unit: D = 0
+                        inl[0][m][r] += d;
+                        inl[1][m][r] = fmaf(d, au0, inl[1][m][r]);         // au0 = 0 at t = 0
+                        inl[2][m][r] = fmaf(d, au1, inl[2][m][r]);
+                        inl[3][m][r] = fmaf(d, m0, inl[3][m][r]);
+                    }
+                }
                 continue;
             }
             // ---- gate pre-activations
@@ -371,7 +398,26 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
             }
         }
     }
-    if (MODE == 2) return;
+    if (MODE == 2) {                               // g cb = g cc tap 1 | g cv tap 0 | g cv tap 1 | g cc tap 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float v = row_sum16(inl[q][m][r]);
+                    if (n == 0) atomicAdd(gwl + q * H + chan_of(m, g, r), v);      // gwl | gbl: 256 contiguous floats
+                }
+        __syncthreads();
+        if (tid < 256) {
+            const float v = gwl[tid];
+            const int o = tid & 63;
+            if (tid < 64) { atomicAdd(a.gP + a.y.cb + o, v); atomicAdd(a.gP + a.y.cc + H + o, v); }
+            else if (tid < 192) atomicAdd(a.gP + a.y.cv + tid - 64, v);
+            else atomicAdd(a.gP + a.y.cc + o, v);
+        }
+        return;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -507,13 +553,13 @@ size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp) {
     return al256((size_t)g.L * LDS_REC) + al256((size_t)(g.L + 1) * LDS_DG) + (size_t)(g.L + 3) * row;
 }
 
-// after the head's backward has left d skip (fp32, (B, S, Tp)): the gated layers.  Leaves d h_0 in dhs rows 0..H-1 of every
-// utterance (nothing else of dhs is touched), dcond, and the wd / bd / bx / wup sections of gpacked.
-int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const void* hs_bf16,
-                       const float* dskip, float* dhs, float* dcond, float* gpacked, void* scratch, int B, int n_frames, long Tp,
-                       hipStream_t st) {
+// after the head's backward has left d skip (fp32, (B, S, Tp)): the gated layers and the input layer.  Fills dcond and the
+// wd / bd / bx / wup / cb / cv / cc sections of gpacked (zeroed by the caller).
+int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
+                       const void* hs_bf16, const float* dskip, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
+                       long Tp, hipStream_t st) {
     BwArgs a;
-    a.P = packed; a.y = y; a.cond = cond; a.hs = reinterpret_cast<const unsigned short*>(hs_bf16); a.dhs = dhs;
+    a.P = packed; a.y = y; a.cond = cond; a.audio = audio; a.hs = reinterpret_cast<const unsigned short*>(hs_bf16);
     unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
     const size_t row = al256((size_t)B * Tp * 256);
     unsigned short* wrec = reinterpret_cast<unsigned short*>(p); p += al256((size_t)g.L * LDS_REC);

@@ -988,9 +988,9 @@ int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* pac
 // fused per-layer backward of the BL6 class in the mixed-precision mode (csrc/swn_bwd_bl6.hip)
 bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames);
 size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp);
-int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const void* hs_bf16,
-                       const float* dskip, float* dhs, float* dcond, float* gpacked, void* scratch, int B, int n_frames, long Tp,
-                       hipStream_t st);
+int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
+                       const void* hs_bf16, const float* dskip, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
+                       long Tp, hipStream_t st);
 
 namespace {
 
@@ -1084,7 +1084,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     // ---- layers, last to first
     if (hs_bf16) {
         if (drop || !swn_bl6_bwd_supported(g, B, Tp, n_frames)) return SWN_E_UNSUPPORTED;
-        const int rcl = swn_bl6_bwd_layers(g, y, packed, cond, hs_bf16, dskip, dhs, dcond, gpacked, dxm, B, n_frames, Tp, st);
+        const int rcl = swn_bl6_bwd_layers(g, y, packed, cond, reinterpret_cast<const float*>(audio), hs_bf16, dskip, dcond, gpacked, dxm,
+                                           B, n_frames, Tp, st);
         if (rcl < 0) return rcl;
     }
     for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
@@ -1137,8 +1138,9 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             }
         }
     }
-    // ---- input layer
-    if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_LAPLACE>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
+    // ---- input layer (the fused layer path has done it from its accumulators)
+    if (hs_bf16) {}
+    else if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_LAPLACE>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
     else hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_SOFTMAX>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
     // ---- frame-rate front end: cond = Wx . C ; C = conv_aux(scale_in(aux))
     {
