@@ -91,6 +91,15 @@ int    swn_pack_params(const swn_net_desc* d, const float* const* tensors_host, 
  *   packed_dev   swn_packed_floats() floats, overwritten (padding zeroed); bit-identical to swn_pack_params      */
 int    swn_pack_params_device(const swn_net_desc* d, const float* const* tensors_dev, int n_tensors,
                               float* packed_dev, size_t packed_floats, void* stream);
+/* The way back for a training step: gradients in the packed layout (swn_backward*) -> the gradient of every parameter
+ * tensor in the reference's shapes, i.e. the chain rule through the pack-time folds, in one launch
+ * (csrc/swn_unfold_dev.hip; the torch-op version is nets/_autograd.py unfold_packed_grads).
+ *   tensors_dev  HOST array of n_tensors DEVICE pointers: the live parameters (state_dict order)
+ *   grads_dev    HOST array of n_tensors DEVICE pointers: contiguous fp32 outputs of the same shapes, overwritten;
+ *                a NULL entry skips that tensor (requires_grad = False)
+ * SWN_E_UNSUPPORTED with aux_conv2d_flag and seg > 1 (callers keep the torch path there). */
+int    swn_unfold_grads_device(const swn_net_desc* d, const float* gpacked_dev, const float* const* tensors_dev,
+                               float* const* grads_dev, int n_tensors, void* stream);
 
 /* ---- frame-rate front end  (cswnv_shift1.py:193,297 / dswnv.py:252,302) ---------------
  * scale_in -> conv_aux (two-sided dilated k=3 stack) -> hoisted in_x:

@@ -82,6 +82,7 @@ SIGNATURES = {
     "swn_forward_drop_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward_drop": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
+    "swn_unfold_grads_device": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "swn_backward_bf16_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_backward_bf16": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -83,6 +83,86 @@ __global__ __launch_bounds__(256) void conv1d_same_kernel(
     }
 }
 
+// The same convolution for ks == 3 with the workgroup's operands staged in LDS: the 64 frames (+ halo) of ALL input
+// channels and the 16 output channels' weight rows are fetched once, coalesced, and the multiply-adds then run without a
+// memory wait in the loop.  (The kernel above pays one L2 round trip per eight input channels for x and streams ~1 MB of
+// weights through the scalar cache, which thrashes: 120 us for 1 200 frames at cin = 162; staging x alone changed
+// nothing.)  Weights lie as wl[wave][ci*3 + k][4 outputs]: one broadcast 16-byte read serves the wave's four outputs.
+// Same (ci ascending, k ascending) chain per output, so the results are bit-identical to conv1d_same_kernel.
+__global__ __launch_bounds__(256) void conv1d_same_lds_kernel(
+    const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+    float* __restrict__ out, int cin, int cout, int dil, int n_frames) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int PW = 64 + 2 * dil, J = cin * 3;
+    float* wl = lds;                                       // [4][J][4]
+    float* xs = lds + 16 * J;                              // [cin][PW]
+    const int lane = threadIdx.x & 63;
+    const int cg = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int f0 = blockIdx.x * 64, b = blockIdx.z;
+    {
+        // eight rows (sixteen loads) in flight per wave before anything is written: a load-store-load chain per element
+        // would pay one L2 round trip per row
+        const __amdgpu_buffer_rsrc_t rI = rsrc_of(in + (size_t)b * cin * n_frames);
+        const int fa = f0 - dil + lane, fb = fa + 64;
+        const unsigned oa = (fa >= 0 && fa < n_frames) ? (unsigned)(fa * 4) : SWN_OOB;
+        const unsigned ob = (lane + 64 < PW && fb >= 0 && fb < n_frames) ? (unsigned)(fb * 4) : SWN_OOB;
+        for (int c0 = cg; c0 < cin; c0 += 32) {
+            float va[8], vb[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ci = c0 + 4 * u;
+                const unsigned ro = ci < cin ? (unsigned)(ci * n_frames * 4) : SWN_OOB;
+                va[u] = bld1(rI, ((oa | ro) & SWN_OOB) ? SWN_OOB : oa + ro);
+                vb[u] = bld1(rI, ((ob | ro) & SWN_OOB) ? SWN_OOB : ob + ro);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int ci = c0 + 4 * u;
+                if (ci < cin) { xs[ci * PW + lane] = va[u]; if (lane + 64 < PW) xs[ci * PW + lane + 64] = vb[u]; }
+            }
+        }
+        const __amdgpu_buffer_rsrc_t rW = rsrc_of(w);
+        for (int q = 0; q < 4; ++q) {                      // this wave stages output `cg` of every wave's group of four
+            const int co = blockIdx.y * 16 + 4 * q + cg;
+            const unsigned ro = co < cout ? (unsigned)((size_t)co * J * 4) : SWN_OOB;
+            for (int j0 = 0; j0 < J; j0 += 512) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = j0 + lane + 64 * u; v[u] = bld1(rW, (j < J && ro != SWN_OOB) ? ro + (unsigned)(j * 4) : SWN_OOB); }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { const int j = j0 + lane + 64 * u; if (j < J) wl[(q * J + j) * 4 + cg] = v[u]; }
+            }
+        }
+    }
+    __syncthreads();
+    const int co0 = blockIdx.y * 16 + 4 * cg;
+    if (co0 >= cout) return;
+    float acc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = (co0 + r < cout) ? bias[co0 + r] : 0.f;
+    const float* xp = xs + lane;
+    const float4* wq = reinterpret_cast<const float4*>(wl) + (size_t)cg * J;
+#pragma unroll 4
+    for (int ci = 0; ci < cin; ++ci) {
+        float x[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) x[k] = xp[ci * PW + k * dil];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float4 wv4 = wq[ci * 3 + k];
+            const float wv[4] = {wv4.x, wv4.y, wv4.z, wv4.w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = fmaf(wv[r], x[k], acc[r]);
+        }
+    }
+    const int f = f0 + lane;
+    if (f < n_frames) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+            if (co0 + r < cout) out[((size_t)b * cout + co0 + r) * n_frames + f] = acc[r];
+    }
+}
+
 // cond[b][f][n] = sum_c Wx[n][c] * C[b][c][f]     (M = frames of one utterance, N, Kd = A0)
 // 64x64 tile, BK = 16, 256 threads x (4x4) outputs, fp32 FMA chains in ascending c.
 __global__ __launch_bounds__(256) void cond_gemm_kernel(
@@ -96,22 +176,29 @@ __global__ __launch_bounds__(256) void cond_gemm_kernel(
     const int tm = (tid & 15) * 4, tn = (tid >> 4) * 4;
     const float* Cb = C + (size_t)b * A0 * n_frames;
     float acc[4][4] = {};
-    for (int k0 = 0; k0 < A0; k0 += 16) {
-        // A tile: 16 k x 64 m, m contiguous in memory
-        for (int e = tid; e < 16 * 64; e += 256) {
-            const int kk = e >> 6, mm = e & 63;
+    // the next k-tile's operands are fetched into registers before the current tile's multiply-adds (the loop used to pay
+    // one L2 round trip per 16 k); same ascending-k chains
+    float ra[4]; float4 rb;
+    const int nn = tid >> 2, kq = (tid & 3) * 4;
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int e = tid + 256 * i, kk = e >> 6, mm = e & 63;
             const int k = k0 + kk, m = m0 + mm;
-            As[kk][mm] = (k < A0 && m < n_frames) ? Cb[(size_t)k * n_frames + m] : 0.f;
+            ra[i] = (k < A0 && m < n_frames) ? Cb[(size_t)k * n_frames + m] : 0.f;
         }
-        // B tile: 64 n x 16 k, k contiguous in memory (rows padded to A0p, zero filled)
-        {
-            const int nn = tid >> 2, kq = (tid & 3) * 4;
-            const int n = n0 + nn, k = k0 + kq;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < N && k < A0p) v = *reinterpret_cast<const float4*>(Wx + (size_t)n * A0p + k);
-            Bs[kq + 0][nn] = v.x; Bs[kq + 1][nn] = v.y; Bs[kq + 2][nn] = v.z; Bs[kq + 3][nn] = v.w;
-        }
+        const int n = n0 + nn, k = k0 + kq;
+        rb = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < N && k < A0p) rb = *reinterpret_cast<const float4*>(Wx + (size_t)n * A0p + k);
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < A0; k0 += 16) {
+        // A tile: 16 k x 64 m, m contiguous in memory ; B tile: 64 n x 16 k, k contiguous (rows padded to A0p, zero filled)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { const int e = tid + 256 * i; As[e >> 6][e & 63] = ra[i]; }
+        Bs[kq + 0][nn] = rb.x; Bs[kq + 1][nn] = rb.y; Bs[kq + 2][nn] = rb.z; Bs[kq + 3][nn] = rb.w;
         __syncthreads();
+        if (k0 + 16 < A0) fetch(k0 + 16);
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const float4 a = *reinterpret_cast<const float4*>(&As[kk][tm]);
@@ -174,8 +261,22 @@ extern "C" int swn_frontend(const swn_net_desc* d, const float* packed, const fl
     cur += bt * g.n_aux;
     for (int i = 0; i < g.auxl; ++i) {
         dim3 grid((n_frames + 63) / 64, (g.aux_cout[i] + 15) / 16, batch);
-        hipLaunchKernelGGL(conv1d_same_kernel<4>, grid, dim3(256), 0, st, src, packed + y.aux_w[i],
-                           packed + y.aux_b[i], cur, g.aux_cin[i], g.aux_cout[i], g.auxk, g.aux_dil[i], n_frames);
+        const size_t lds = ((size_t)g.aux_cin[i] * (64 + 2 * g.aux_dil[i]) + 16 * (size_t)g.aux_cin[i] * 3) * sizeof(float);
+        bool staged = g.auxk == 3 && lds <= 150 * 1024;
+        if (staged && lds > 48 * 1024) {
+            static size_t granted = 0;                     // the attribute is per function: raise it when a larger geometry comes
+            if (lds > granted) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv1d_same_lds_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess) granted = lds;
+                else staged = false;
+            }
+        }
+        if (staged)
+            hipLaunchKernelGGL(conv1d_same_lds_kernel, grid, dim3(256), lds, st, src, packed + y.aux_w[i],
+                               packed + y.aux_b[i], cur, g.aux_cin[i], g.aux_cout[i], g.aux_dil[i], n_frames);
+        else
+            hipLaunchKernelGGL(conv1d_same_kernel<4>, grid, dim3(256), 0, st, src, packed + y.aux_w[i],
+                               packed + y.aux_b[i], cur, g.aux_cin[i], g.aux_cout[i], g.auxk, g.aux_dil[i], n_frames);
         src = cur;
         cur += bt * g.aux_cout[i];
     }

@@ -32,6 +32,8 @@ struct TimeGemm {
     int XT;                                         // X is valid on [0, XT) (0: same as T)
     int nb;                                         // batch size (set by the launcher of the XCD-ordered kernel)
     const float* bias; int relu;                    // optional: v = acc + bias[m], then max(v, 0)  (forward 1x1 layers)
+    int ksplit;                                     // > 1 (bf16 64x64 kernel only): the k range is cut into ksplit parts, one per
+                                                    // workgroup, added atomically into a zeroed Y (frame-rate GEMMs: few tiles, long k)
 };
 
 // Epilogue of the time contractions: relu mask, dropout multiplier, accumulate, store - for NV results of one thread.
@@ -156,20 +158,23 @@ template <bool XMUL>
 __global__ __launch_bounds__(256) void time_gemm_bf16_kernel(const TimeGemm g) {
     __shared__ __attribute__((aligned(16))) unsigned As[64][SWN_MMB_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned Bs[64][SWN_MMB_PITCH];
-    const int b = blockIdx.z, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
+    const int nsp = g.ksplit > 1 ? g.ksplit : 1;
+    const int b = blockIdx.z / nsp, ksp = blockIdx.z - b * nsp, t0 = blockIdx.x * 64, m0 = blockIdx.y * 64;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const __amdgpu_buffer_rsrc_t rA = rsrc_of(g.A), rX = rsrc_of(g.X + (size_t)b * g.x_sb);
     const __amdgpu_buffer_rsrc_t rM = rsrc_of(XMUL ? g.xmul + (size_t)b * g.xm_sb : g.A);
-    const int Kd = g.taps * g.KC;
+    const int Kall = g.taps * g.KC;
+    const int per = ((Kall + 31) / 32 + nsp - 1) / nsp * 32;      // k per part, whole k-tiles
+    const int kbeg = ksp * per, Kd = kbeg + per < Kall ? kbeg + per : Kall;
     swn_f32x4 acc[4] = {};
     const int kp = tid & 15, tt = tid & 63, kq = tid >> 6;
     const int dtap = 32 / g.KC, dc = 32 - dtap * g.KC;          // a k-tile step in (tap, c) coordinates
     int tapA[2], cA[2], tapB[4][2], cB[4][2];
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
-        const int kk = 2 * kp + e; tapA[e] = kk / g.KC; cA[e] = kk - tapA[e] * g.KC;
+        const int kk = kbeg + 2 * kp + e; tapA[e] = kk / g.KC; cA[e] = kk - tapA[e] * g.KC;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) { const int kb = 2 * (kq + 4 * i) + e; tapB[i][e] = kb / g.KC; cB[i][e] = kb - tapB[i][e] * g.KC; }
+        for (int i = 0; i < 4; ++i) { const int kb = kbeg + 2 * (kq + 4 * i) + e; tapB[i][e] = kb / g.KC; cB[i][e] = kb - tapB[i][e] * g.KC; }
     }
     unsigned arow[4];
 #pragma unroll
@@ -198,8 +203,8 @@ __global__ __launch_bounds__(256) void time_gemm_bf16_kernel(const TimeGemm g) {
         }
     };
 #pragma unroll
-    for (int u = 0; u < NST; ++u) fetch(32 * u, ra[u], rb[u], rm[u]);
-    for (int k0 = 0; k0 < Kd; k0 += 32 * NST) {
+    for (int u = 0; u < NST; ++u) fetch(kbeg + 32 * u, ra[u], rb[u], rm[u]);
+    for (int k0 = kbeg; k0 < Kd; k0 += 32 * NST) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {                 // tiles past Kd hold zeros: no branch inside the loop
 #pragma unroll
@@ -220,6 +225,12 @@ __global__ __launch_bounds__(256) void time_gemm_bf16_kernel(const TimeGemm g) {
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int i = 0; i < 4; ++i) { mrow[4 * mt + i] = m0 + swn_mma_row(lane, mt, i); v[4 * mt + i] = acc[mt][i]; }
+    if (nsp > 1) {                                  // partial sums of one k part (no bias / mask / scale in this form)
+        float* Y = g.Y + (size_t)b * g.y_sb + t;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) if (mrow[i] < g.M && t < g.T) atomicAdd(Y + (size_t)mrow[i] * g.y_sm, v[i]);
+        return;
+    }
     tg_epilogue<16>(g, b, mrow, t, v);
 }
 
@@ -859,6 +870,18 @@ void launch_time(const TimeGemm& g, int B, hipStream_t st) {
             if (g.a_sc == 1) hipLaunchKernelGGL(time_gemm_bf16t_kernel<true>, big, dim3(256), 0, st, h);
             else hipLaunchKernelGGL(time_gemm_bf16t_kernel<false>, big, dim3(256), 0, st, h);
             return;
+        }
+        // frame-rate GEMMs (a few hundred columns, k in the hundreds to thousands): too few tiles to fill the chip and a long
+        // latency-bound k loop per tile -> cut k over several workgroups
+        const int wgs = (int)(grid.x * grid.y) * B, nk = (g.taps * g.KC + 31) / 32;
+        if (!g.xmul && !g.mask && !g.ymul && !g.bias && !g.accumulate && wgs < 512 && nk >= 8 && g.y_sm == g.T &&
+            g.y_sb == (long)g.M * g.T) {
+            int ks = 1024 / wgs; if (ks > nk / 3) ks = nk / 3; if (ks > 8) ks = 8;
+            if (ks > 1 && hipMemsetAsync(g.Y, 0, (size_t)B * g.M * g.T * sizeof(float), st) == hipSuccess) {
+                TimeGemm h = g; h.ksplit = ks;
+                hipLaunchKernelGGL(time_gemm_bf16_kernel<false>, dim3(grid.x, grid.y, B * ks), dim3(256), 0, st, h);
+                return;
+            }
         }
         if (g.xmul) hipLaunchKernelGGL(time_gemm_bf16_kernel<true>, grid, dim3(256), 0, st, g);
         else hipLaunchKernelGGL(time_gemm_bf16_kernel<false>, grid, dim3(256), 0, st, g);

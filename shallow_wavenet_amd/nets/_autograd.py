@@ -97,6 +97,36 @@ def unfold_packed_grads(cfg: NetConfig, gp: torch.Tensor, params: Dict[str, torc
     return g
 
 
+def unfold_packed_grads_device(net: HipNet, gp: torch.Tensor, params, want) -> List:
+    """the same map by ONE launch (swn_unfold_grads_device) into views of one flat buffer; `want[i]` False -> None.
+    Returns None where the library does not cover the geometry (aux_conv2d_flag with seg > 1)."""
+    import ctypes
+    from .. import _lib
+    cfg = net.cfg
+    if cfg.kind == "laplace" and cfg.aux_conv2d_flag and cfg.seg > 1:
+        return None
+    n = len(params)
+    sizes = [p.numel() if w else 0 for p, w in zip(params, want)]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=gp.device)
+    base, off = flat.data_ptr(), 0
+    gptr, out = [], []
+    for p, sz in zip(params, sizes):
+        if sz:
+            gptr.append(base + 4 * off)
+            out.append(flat[off:off + sz].view(p.shape))
+            off += sz
+        else:
+            gptr.append(None)
+            out.append(None)
+    pp = (ctypes.c_void_p * n)(*[p.data_ptr() for p in params])
+    gg = (ctypes.c_void_p * n)(*gptr)
+    with torch.cuda.device(gp.device):
+        _lib.check(net.lib.swn_unfold_grads_device(ctypes.byref(net.desc), ctypes.c_void_p(gp.data_ptr()), pp, gg, n,
+                                                   ctypes.c_void_p(torch.cuda.current_stream(gp.device).cuda_stream)),
+                   "unfold_grads_device")
+    return out
+
+
 class StackFunction(torch.autograd.Function):
     """raw = stack(aux, audio; parameters) -> (B, n_out, Tp); backward fills every parameter's grad."""
 
@@ -106,16 +136,20 @@ class StackFunction(torch.autograd.Function):
         raw, saved = net.forward_train(aux, audio, drop=getattr(module, "_pending_drop", None))
         module._pending_drop = None
         ctx.net, ctx.saved, ctx.module = net, saved, module
-        ctx.names = [k for k, _ in module.named_parameters()]
+        ctx.plist = [p.detach() for p in params]       # Module.parameters() order = state_dict order
         return raw
 
     @staticmethod
     def backward(ctx, grad_raw):
         gp = ctx.net.backward(ctx.saved, grad_raw)
-        pd = {k: p.detach() for k, p in ctx.module.named_parameters()}
-        grads = unfold_packed_grads(ctx.net.cfg, gp, pd)
-        out = [grads[k].reshape(pd[k].shape).contiguous() if ctx.needs_input_grad[3 + i] else None
-               for i, k in enumerate(ctx.names)]
+        want = ctx.needs_input_grad[3:]
+        fp32 = all(p.dtype == torch.float32 and p.is_contiguous() for p in ctx.plist)
+        out = unfold_packed_grads_device(ctx.net, gp, ctx.plist, want) if (fp32 and ctx.module.device_unfold) else None
+        if out is None:                                # torch-op version (aux_conv2d_flag, or switched off for A/B tests)
+            names = [k for k, _ in ctx.module.named_parameters()]
+            pd = dict(zip(names, ctx.plist))
+            grads = unfold_packed_grads(ctx.net.cfg, gp, pd)
+            out = [grads[k].reshape(pd[k].shape).contiguous() if want[i] else None for i, k in enumerate(names)]
         return (None, None, None, *out)
 
 

@@ -80,20 +80,36 @@ class EngineMixin:
     place (load_state_dict, optimizer step, .to()/.cuda()); SURVEY.md 8b 'Checkpoint / ownership'."""
 
     _cfg: NetConfig
+    device_unfold = True      # packed gradients -> p.grad by one launch (False: the torch-op version, nets/_autograd.py)
+
+    def _param_slots(self):
+        """[(module._parameters, name)] in state_dict order, built once: walking the module tree on every call costs more
+        host time than a BL6 layer kernel runs.  Reading the Parameter through its slot sees a replaced object; a module
+        ADDED after the first call is not seen (the reference's models are fixed after construction)."""
+        slots = self.__dict__.get("_slots")
+        if slots is None:
+            slots = [(m._parameters, k) for m in self.modules() for k, v in m._parameters.items() if v is not None]
+            self.__dict__["_slots"] = slots
+        return slots
+
+    def _param_list(self):
+        return [d[k] for d, k in self._param_slots()]
 
     def _engine_key(self):
-        return tuple((p.data_ptr(), p._version, str(p.device)) for p in self.parameters())
+        ps = self._param_list()
+        return (ps[0].device, tuple((p.data_ptr(), p._version) for p in ps))
 
     def _engine(self) -> HipNet:
-        dev = next(self.parameters()).device
+        ps = self._param_list()
+        dev = ps[0].device
         if dev.type != "cuda":
             raise RuntimeError(
                 f"{type(self).__name__}: parameters are on {dev}; the MI355X build has no CPU path - "
                 "call model.cuda() on a machine with a HIP device")
-        key = self._engine_key()
+        key = (dev, tuple((p.data_ptr(), p._version) for p in ps))
         cache = self.__dict__.get("_engine_cache")
         if cache is None or cache[0] != key:
-            tensors = list(self.state_dict().values())
+            tensors = ps                       # Module.parameters() order is state_dict order (no buffers in these models)
             if cache is not None and cache[1].device == dev:
                 # parameters changed (optimizer step, load_state_dict): re-lay them out on the device, in place
                 net = cache[1]

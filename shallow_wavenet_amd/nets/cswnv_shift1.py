@@ -114,11 +114,11 @@ class CSWNV(EngineMixin, nn.Module):
         two = self.dilation_depth * self.dilation_repeat <= 2
         if self.do_prob > 0 and self.training and (do or two):
             drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob, draw_x=bool(do))
-        if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list())):
             # training: HIP forward + HIP backward behind autograd Functions (nets/_autograd.py)
             from shallow_wavenet_amd.nets._autograd import LaplaceHeadFunction, StackFunction
             self._pending_drop = drop
-            raw = StackFunction.apply(self, aux, audio, *self.parameters())
+            raw = StackFunction.apply(self, aux, audio, *self._param_list())
             mu, b, log_b, a, b_clip, log_b_clip, flag = LaplaceHeadFunction.apply(net, raw, clip)
             a = a if self.lpc > 0 else None
             if not clip:

@@ -131,10 +131,10 @@ class DSWNV(EngineMixin, nn.Module):
         drop = None
         if do and self.do_prob > 0 and self.training:          # nn.Dropout acts in training mode only
             drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob)
-        if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())):
+        if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list())):
             from shallow_wavenet_amd.nets._autograd import StackFunction
             self._pending_drop = drop
-            raw = StackFunction.apply(self, aux, idx, *self.parameters())
+            raw = StackFunction.apply(self, aux, idx, *self._param_list())
         else:
             raw, _ = net.forward(aux, idx)
         return raw.transpose(1, 2)

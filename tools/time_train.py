@@ -46,10 +46,13 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     for _ in range(2): step()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    import time
     e0.record()
     n = 5
+    h0 = time.perf_counter()
     for _ in range(n): step()
+    host_ms = (time.perf_counter() - h0) * 1e3 / n      # time the host needs to ISSUE a step (no sync inside)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     macs_fwd = (cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.S * cfg.S + cfg.n_out * cfg.S) * B * Tp
-    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}{' chain' if CHAIN else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops)")
+    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}{' chain' if CHAIN else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops); host issue {host_ms:.2f} ms/step")
