@@ -803,15 +803,27 @@ __global__ __launch_bounds__(256) void input_bwd_kernel(const GateBwd a, float* 
     const float* P = a.P;
     const float* dh0 = a.dhs + ((size_t)b * (g.L + 1)) * H * a.Tp + (size_t)o * a.Tp;
     float scb = 0.f, sv[8] = {0.f}, sc[8] = {0.f};
+    // the channel's constants stay in registers (they were re-read from memory for every position: 433 us at REF6)
+    float kv[8], kc[8];
+    const float kb = P[a.y.cb + o];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { kv[k] = (KIND == SWN_KIND_LAPLACE && k < K) ? P[a.y.cv + (size_t)k * H + o] : 0.f;
+                                  kc[k] = (KIND == SWN_KIND_LAPLACE && k < K) ? P[a.y.cc + (size_t)k * H + o] : 0.f; }
     for (int t = threadIdx.x; t < a.Tp; t += 256) {
-        float pre = P[a.y.cb + o];
+        float pre = kb;
         if (KIND == SWN_KIND_LAPLACE) {
             const float* au = reinterpret_cast<const float*>(a.audio) + (size_t)b * (a.Tp + g.seg - 1);
             const int ai = t + g.seg - 1;
-            for (int k = 0; k < K; ++k) { const int r = ai - (K - 1 - k); if (r >= 0) pre += fmaf(P[a.y.cv + (size_t)k * H + o], au[r], P[a.y.cc + (size_t)k * H + o]); }
-            const float d = dh0[t] / ((1.f + fabsf(pre)) * (1.f + fabsf(pre)));
+            float x[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); x[k] = (k < K && r >= 0) ? au[r] : 0.f; }
+            const float dh = dh0[t];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); if (k < K && r >= 0) pre += fmaf(kv[k], x[k], kc[k]); }
+            const float d = dh / ((1.f + fabsf(pre)) * (1.f + fabsf(pre)));
             scb += d;
-            for (int k = 0; k < K && k < 8; ++k) { const int r = ai - (K - 1 - k); if (r >= 0) { sv[k] = fmaf(d, au[r], sv[k]); sc[k] += d; } }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); if (k < K && r >= 0) { sv[k] = fmaf(d, x[k], sv[k]); sc[k] += d; } }
         } else {
             const int* au = reinterpret_cast<const int*>(a.audio) + (size_t)b * a.Tp;
             int idxs[8];
@@ -825,10 +837,34 @@ __global__ __launch_bounds__(256) void input_bwd_kernel(const GateBwd a, float* 
             for (int k = 0; k < K && k < 8; ++k) if (idxs[k] >= 0) atomicAdd(gP + a.y.ct + ((size_t)k * g.Q + idxs[k]) * H + o, d);
         }
     }
-    // block reduction through atomics (H blocks x B): cheap at this size
-    atomicAdd(gP + a.y.cb + o, scb);
-    if (KIND == SWN_KIND_LAPLACE)
-        for (int k = 0; k < K && k < 8; ++k) { atomicAdd(gP + a.y.cv + (size_t)k * H + o, sv[k]); atomicAdd(gP + a.y.cc + (size_t)k * H + o, sc[k]); }
+    // block reduction, then one atomic per value and block (every thread used to add its own partial: 256 x H x B
+    // atomics onto H addresses per section)
+    __shared__ float red[4][17];
+    auto wave_sum = [](float v) {
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) v += __shfl_down(v, sft);
+        return v;
+    };
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    scb = wave_sum(scb);
+    if (lane == 0) red[wv][0] = scb;
+    if (KIND == SWN_KIND_LAPLACE) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const float a1 = wave_sum(sv[k]), a2 = wave_sum(sc[k]);
+            if (lane == 0) { red[wv][1 + k] = a1; red[wv][9 + k] = a2; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 17) {
+        const int i = threadIdx.x;
+        const float v = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        if (i == 0) atomicAdd(gP + a.y.cb + o, v);
+        else if (KIND == SWN_KIND_LAPLACE) {
+            const int k = (i - 1) & 7;
+            if (k < K) atomicAdd(gP + (i <= 8 ? a.y.cv : a.y.cc) + (size_t)k * H + o, v);
+        }
+    }
 }
 
 // ---- Laplace head backward: grads wrt (mu, b, logb, a) time-major -> grad wrt raw (B, NO, Tp)
