@@ -226,12 +226,14 @@ int    swn_backward(const swn_net_desc* d, const float* packed_dev, const float*
                     const float* hs_dev, const float* grad_out_dev, int batch, int n_frames,
                     float* work_dev, float* gpacked_dev, void* stream);
 /* The same backward after a bf16 forward of the BL6 class in the mixed-precision mode (swn_train_set_precision(1)), with
- * the gated layers fused per layer (csrc/swn_bwd_bl6.hip): recompute, gate derivative, highway carry, conditioning and
- * the layer above's data gradient in one launch per layer that reads the bf16 time-major hidden states directly.
- *   work_bf16_dev  the work buffer swn_forward_bf16 filled; fwd_work_dev its fp32 expansion (swn_bf16_work_to_f32), still
- *                  read by the head's and the input layer's backward
+ * everything at sample rate fused (csrc/swn_bwd_bl6.hip): one launch for the head (recompute of relu(skip) / relu(out_1),
+ * d out_1, d skip, g out_2), one per gated layer (the layer above's data gradient, the skip path's share, recompute, gate
+ * derivative, highway carry, conditioning) plus one that also does the input layer, and one for every other weight
+ * gradient - all reading the bf16 time-major hidden states directly.
+ *   work_bf16_dev  the work buffer swn_forward_bf16 filled
+ *   fwd_work_dev   ignored (may be NULL): the fp32 expansion of swn_bf16_work_to_f32 is not needed on this path
  *   work_dev       swn_backward_bf16_work_floats() floats (0 = geometry / size not covered: seg == 1, 16 <= U <= 112,
- *                  Laplace, BL6 stack; the call then returns SWN_E_UNSUPPORTED and the caller uses swn_backward)      */
+ *                  Laplace, BL6 stack, S = 128; the call then returns SWN_E_UNSUPPORTED and the caller uses swn_backward) */
 size_t swn_backward_bf16_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_backward_bf16(const swn_net_desc* d, const float* packed_dev, const float* aux_dev, const float* cond_dev,
                          const float* fe_work_dev, const void* audio_dev, const float* fwd_work_dev,

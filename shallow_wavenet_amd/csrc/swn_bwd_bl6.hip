@@ -125,31 +125,6 @@ __global__ void pack_wdg_kernel(const float* __restrict__ wd, const float* __res
     dst[e] = f2bf(v);
 }
 
-// d skip pre-activation, fp32 channel-major (B, 128, Tp) as the generic head backward leaves it -> bf16 time-major
-// [B][Tp][128], the B-fragment layout of the layer kernel
-__global__ __launch_bounds__(256) void dskip_tm_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, int Tp,
-                                                       int tiles_per_b) {
-    __shared__ float tl[128][65];
-    const int tid = threadIdx.x;
-    const int b = blockIdx.x / tiles_per_b, t0 = (blockIdx.x - b * tiles_per_b) * 64;
-#pragma unroll 8
-    for (int i = 0; i < 32; ++i) {
-        const int e = tid + 256 * i, ch = e >> 6, t = t0 + (e & 63);
-        tl[ch][e & 63] = t < Tp ? src[((size_t)b * 128 + ch) * Tp + t] : 0.f;
-    }
-    __syncthreads();
-    const int row = tid & 63, qu = tid >> 6, t = t0 + row;
-    if (t >= Tp) return;
-#pragma unroll
-    for (int c8 = 0; c8 < 4; ++c8) {
-        const int ch0 = (qu * 4 + c8) * 8;
-        uint4 v;
-        v.x = pack2(tl[ch0][row], tl[ch0 + 1][row]);     v.y = pack2(tl[ch0 + 2][row], tl[ch0 + 3][row]);
-        v.z = pack2(tl[ch0 + 4][row], tl[ch0 + 5][row]); v.w = pack2(tl[ch0 + 6][row], tl[ch0 + 7][row]);
-        *reinterpret_cast<uint4*>(dst + ((size_t)b * Tp + t) * 128 + ch0) = v;
-    }
-}
-
 // ---- one gated layer ----------------------------------------------------------------------------------------------
 // MODE 0: top layer l = L-1 (d h_L = skip share only)   1: inner layer   2: l = -1: d h_0 = E_0 + Wd_0^T (*) da_0 and,
 // straight from the accumulators, the input layer's backward (h_0 = softsign(cb + lifted causal taps), cswnv_shift1.py:
@@ -432,23 +407,37 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
     else if (tid - 128 < a.U) atomicAdd(a.gP + a.y.wup + tid - 128, gwl[tid - 128]);
 }
 
-// ---- weight gradient of the dilated convs, all layers in one launch --------------------------------------------------
-// g Wd_l[o2][k] += sum_t da_l[o2][t] * X_l[k][t],  X_l(t) = [h_l(t - d_l) ; h_l(t)],  g bd_l[o2] += sum_t da_l[o2][t].
-// Workgroup = (time split, layer); per step a 32-position tile of both operands is staged in LDS in the layout it has in
+// ---- weight gradients, all of them in one launch --------------------------------------------------------------------------
+// G[m][k] += sum_t A[t][m] * X[t][k]  (128 x 128 per job) and bias[m] += sum_t A[t][m], time the reduction axis:
+//   dil_h of layer l    A = da_l            X(t) = [h_l(t - d_l) ; h_l(t)]
+//   out_skip, 3 jobs    A = dskip           X(t) = [h_{2q+1}(t) ; h_{2q+2}(t)]        (columns 128q.. of the 128 x 384 matrix)
+//   out_1               A = d out_1         X(t) = relu(skip)(t)
+// Workgroup = (time split, job); per step a 32-position tile of both operands is staged in LDS in the layout it has in
 // HBM ([t][128] bf16, 16-byte chunks XOR-swizzled against bank conflicts) and the MFMA fragments - which want the
 // reduction axis t inside a lane - are read with the transposing ds_read_b64_tr_b16.  Wave w owns rows 32w..32w+31 of the
-// 128 x 128 result (16 accumulator tiles); bd comes from an all-ones B fragment.
+// 128 x 128 result (16 accumulator tiles); the bias comes from an all-ones B fragment.
 __device__ __forceinline__ unsigned tile_off(int row, int ch) { return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
-__global__ __launch_bounds__(256) void bl6_wgrad_kernel(const BwArgs a, const int tiles_per_b, const int n_tiles) {
-    __shared__ __attribute__((aligned(16))) unsigned char img[2][2][32 * 256];     // [buffer][da | x][32 rows x 256 B]
+struct WJob {
+    const unsigned short* A;           // [B][Tp][128]
+    const unsigned short* X0; const unsigned short* X1;     // left / right 64 columns of X: rows of rs0 / rs1 elements
+    int rs0, rs1, sh0, sh1;            // row strides (elements) and time shifts (X0 is read at t - sh0, zero before the start)
+    float* out; int ld; float* bias;   // G (row stride ld), bias (may be null)
+};
+constexpr int WG_MAXJOBS = SWN_MAXL + 4;
+struct WgArgs { WJob job[WG_MAXJOBS]; int B, Tp; };
+
+__global__ __launch_bounds__(256) void bl6_wgrad_kernel(const WgArgs a, const int tiles_per_b, const int n_tiles) {
+    __shared__ __attribute__((aligned(16))) unsigned char img[2][2][32 * 256];     // [buffer][A | X][32 rows x 256 B]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int n = lane & 15, g = lane >> 4;
-    const int l = blockIdx.y, dil = a.dil[l];
-    const size_t lstride = (size_t)a.B * a.Tp * H;
-    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
-    const __amdgpu_buffer_rsrc_t rd = make_rsrc(a.da + (size_t)l * lstride * 2, lstride * 4);
+    const WJob& jb = a.job[blockIdx.y];
+    const size_t npos = (size_t)a.B * a.Tp;
     const int lrow = tid >> 4, lch = tid & 15;
+    const bool left = lch < 8;
+    const __amdgpu_buffer_rsrc_t rd = make_rsrc(jb.A, npos * 256);
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(left ? jb.X0 : jb.X1, npos * (size_t)(left ? jb.rs0 : jb.rs1) * 2);
+    const int rs = left ? jb.rs0 : jb.rs1, sh = left ? jb.sh0 : jb.sh1;
     u32x4 vd[2], vx[2];
     auto fetch = [&](int tix) {
         const bool tok = tix < n_tiles;
@@ -459,8 +448,8 @@ __global__ __launch_bounds__(256) void bl6_wgrad_kernel(const BwArgs a, const in
             const int t = t0 + lrow + 16 * i;
             const bool ok = tok && t < a.Tp;
             vd[i] = ld_u4(rd, ok ? (unsigned)((b * a.Tp + t) * 128 + 8 * lch) * 2u : OOB);
-            const int tt = lch < 8 ? t - dil : t;
-            vx[i] = ld_u4(rh, (ok && tt >= 0) ? (unsigned)((b * a.Tp + tt) * H + 8 * (lch & 7)) * 2u : OOB);
+            const int tt = t - sh;
+            vx[i] = ld_u4(rx, (ok && tt >= 0) ? (unsigned)((b * a.Tp + tt) * rs + 8 * (lch & 7)) * 2u : OOB);
         }
     };
     f32x4 acc[2][8], accb[2];
@@ -509,17 +498,220 @@ __global__ __launch_bounds__(256) void bl6_wgrad_kernel(const BwArgs a, const in
         }
         cur ^= 1;
     }
-    float* gw = a.gP + a.y.wd + (size_t)l * 128 * 128;
-    float* gb = a.gP + a.y.bd + (size_t)l * 128;
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * (2 * w + mi) + 4 * g + r;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) atomicAdd(gw + (size_t)row * 128 + 16 * nt + n, acc[mi][nt][r]);
-            if (n == 0) atomicAdd(gb + row, accb[mi][r]);
+            for (int nt = 0; nt < 8; ++nt) atomicAdd(jb.out + (size_t)row * jb.ld + 16 * nt + n, acc[mi][nt][r]);
+            if (n == 0 && jb.bias) atomicAdd(jb.bias + row, accb[mi][r]);
         }
+}
+
+// ---- head: out_2 / out_1 / skip backward ------------------------------------------------------------------------------------
+// Per 64-position tile (8 waves, wave w owns rows 16w..16w+15 of every 128-row product, all four 16-position column tiles):
+//   recompute  s1 = relu(bsk + Wsk . [h_1..h_L]),  r1 = relu(b1 + W1 . s1)                 (what the forward's head kernel kept on chip)
+//   d out_1 = [r1 > 0] . W2^T dY          d skip = [s1 > 0] . W1^T d out_1
+//   g W2 += dY . r1^T, g b2 += sum dY     (the only products with NO <= 16 rows: accumulated here, one column tile per wave)
+//   s1, d out_1, d skip -> bf16 time-major [t][128]: operands of the weight-gradient launch; d skip also feeds the layer kernels.
+// Fragment images (pack_frag / pack_fragT below): A[row][k] row-major in k, [mt][ks][lane][8].
+__global__ void pack_frag_kernel(const float* __restrict__ src, int ld, int rows, int cols, int MT, int KS, unsigned short* __restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= MT * KS * 512) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = (e >> 9) % KS, mt = (e >> 9) / KS;
+    const int r = 16 * mt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+    dst[e] = (r < rows && k < cols) ? f2bf(src[(size_t)r * ld + k]) : (unsigned short)0;
+}
+// transposed source: A[row][k] = W[k][row]
+__global__ void pack_fragT_kernel(const float* __restrict__ src, int ld, int krows, int rcols, int MT, int KS, unsigned short* __restrict__ dst) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= MT * KS * 512) return;
+    const int j = e & 7, lane = (e >> 3) & 63, ks = (e >> 9) % KS, mt = (e >> 9) / KS;
+    const int r = 16 * mt + (lane & 15), k = 32 * ks + 8 * (lane >> 4) + j;
+    dst[e] = (r < rcols && k < krows) ? f2bf(src[(size_t)k * ld + r]) : (unsigned short)0;
+}
+
+constexpr int HB_THREADS = 512, HB_TN = 64, HB_ROW = 272;            // LDS tile pitch in bytes of a [pos][128 bf16] tile
+constexpr int HB_BT = 4 * 12 * 64 * 16;                              // published B fragments of [h_1..h_6] for 64 positions
+constexpr int HB_LDS = HB_BT + 4 * HB_TN * HB_ROW;
+struct HbArgs {
+    const float* P; SwnLayout y;
+    const unsigned short* hs;          // [L+1][B][Tp][64]
+    const float* dY;                   // (B, NO, Tp) fp32: gradient wrt the raw out_2 outputs
+    const unsigned short *wsk, *w1, *w1t, *w2t;        // fragment images [8][12] / [8][4] / [8][4] / [8][1]
+    unsigned short *s1, *do1, *dsk;    // [B][Tp][128] bf16 outputs
+    float* gP;
+    int B, Tp, NO, O1p;
+};
+
+__global__ __launch_bounds__(HB_THREADS, 1) void bl6_head_bwd_kernel(const HbArgs a, const int n_tiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    unsigned char* bt = sm;
+    unsigned char* t1 = sm + HB_BT;                     // relu(skip)
+    unsigned char* t2 = t1 + HB_TN * HB_ROW;            // relu(out_1)
+    unsigned char* t3 = t2 + HB_TN * HB_ROW;            // d out_1
+    unsigned char* t4 = t3 + HB_TN * HB_ROW;            // d skip
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    bf16x8 Ask[12], A1[4], A1T[4], A2T;
+    {
+        const bf16x8* i0 = reinterpret_cast<const bf16x8*>(a.wsk);
+        const bf16x8* i1 = reinterpret_cast<const bf16x8*>(a.w1);
+        const bf16x8* i2 = reinterpret_cast<const bf16x8*>(a.w1t);
+        const bf16x8* i3 = reinterpret_cast<const bf16x8*>(a.w2t);
+#pragma unroll
+        for (int ks = 0; ks < 12; ++ks) Ask[ks] = i0[(w * 12 + ks) * 64 + lane];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { A1[ks] = i1[(w * 4 + ks) * 64 + lane]; A1T[ks] = i2[(w * 4 + ks) * 64 + lane]; }
+        A2T = i3[w * 64 + lane];
+    }
+    float bsk[4], b1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { bsk[r] = a.P[a.y.bsk + 16 * w + 4 * g + r]; b1[r] = a.P[a.y.b1 + 16 * w + 4 * g + r]; }
+    const size_t lstride = (size_t)a.B * a.Tp * H;
+    const int tiles_per_b = (a.Tp + HB_TN - 1) / HB_TN;
+    __amdgpu_buffer_rsrc_t rl[6];
+#pragma unroll
+    for (int qq = 0; qq < 6; ++qq) rl[qq] = make_rsrc(a.hs + (size_t)(1 + qq) * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(a.dY, (size_t)a.B * a.NO * a.Tp * 4);
+    const __amdgpu_buffer_rsrc_t ro[3] = {make_rsrc(a.s1, lstride * 4), make_rsrc(a.do1, lstride * 4), make_rsrc(a.dsk, lstride * 4)};
+    // wave w fetches column tile w & 3, k-steps 6 (w >> 2) .. + 5 of the skip GEMM's B operand, one tile ahead
+    const int cnt = w & 3, ck0 = 6 * (w >> 2);
+    bf16x8 mycol[6];
+    auto fetch_col = [&](int tix) {
+        const int tc = tix < n_tiles ? tix : n_tiles - 1;
+        const int b = tc / tiles_per_b, t = (tc - b * tiles_per_b) * HB_TN + 16 * cnt + n;
+        const unsigned off = (tix < n_tiles && t < a.Tp) ? (unsigned)(b * a.Tp + t) * (H * 2u) + (unsigned)(8 * g) * 2u : OOB;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) { const int ks = ck0 + u; mycol[u] = ld_bf8(rl[ks >> 1], off + 64u * (ks & 1)); }
+    };
+    fetch_col(blockIdx.x);
+    f32x4 acc_w2 = {0.f, 0.f, 0.f, 0.f}, acc_b2 = {0.f, 0.f, 0.f, 0.f};
+    const s16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    const int q = n >> 2, p = n & 3;
+
+    for (int tix = blockIdx.x; tix < n_tiles; tix += gridDim.x) {
+        const int b = tix / tiles_per_b, t0 = (tix - b * tiles_per_b) * HB_TN;
+#pragma unroll
+        for (int u = 0; u < 6; ++u) *reinterpret_cast<bf16x8*>(bt + ((cnt * 12 + ck0 + u) * 64 + lane) * 16) = mycol[u];
+        fetch_col(tix + gridDim.x);
+        // dY in both orientations (tiny: NO <= 16 rows), issued ahead of the GEMMs
+        bf16x8 dyb[4], dya[2];
+        {
+            float v[4][8], u2[2][8];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)             // B operand of W2^T . dY: lane (position, k group): k = output row 8g + j
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int no = 8 * g + j, t = t0 + 16 * nt + n;
+                    v[nt][j] = ld_f1(ry, (no < a.NO && t < a.Tp) ? (unsigned)((b * a.NO + no) * a.Tp + t) * 4u : OOB);
+                }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2)             // A operand of dY . r1^T: lane (row = output row n, k group): 8 consecutive positions
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int t = t0 + 32 * k2 + 8 * g + j;
+                    u2[k2][j] = ld_f1(ry, (n < a.NO && t < a.Tp) ? (unsigned)((b * a.NO + n) * a.Tp + t) * 4u : OOB);
+                }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const u32x4 pk = {pack2(v[nt][0], v[nt][1]), pack2(v[nt][2], v[nt][3]), pack2(v[nt][4], v[nt][5]), pack2(v[nt][6], v[nt][7])};
+                dyb[nt] = __builtin_bit_cast(bf16x8, pk);
+            }
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                const u32x4 pk = {pack2(u2[k2][0], u2[k2][1]), pack2(u2[k2][2], u2[k2][3]), pack2(u2[k2][4], u2[k2][5]), pack2(u2[k2][6], u2[k2][7])};
+                dya[k2] = __builtin_bit_cast(bf16x8, pk);
+            }
+        }
+        __syncthreads();                                                   // (A) bt published
+        // ---- skip = Wsk . [h_1 .. h_L]
+        f32x4 s1v[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            s1v[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 12; ++ks) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bt + ((nt * 12 + ks) * 64 + lane) * 16);
+                s1v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[ks], bf, s1v[nt], 0, 0, 0);
+            }
+        }
+        auto put = [&](unsigned char* tl, const int nt, const f32x4& v) {   // rows 16w + 4g .. + 3 of position 16nt + n
+            uint2 pk; pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]);
+            *reinterpret_cast<uint2*>(tl + (16 * nt + n) * HB_ROW + (16 * w + 4 * g) * 2) = pk;
+        };
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s1v[nt][r] = fmaxf(s1v[nt][r] + bsk[r], 0.f);
+            put(t1, nt, s1v[nt]);
+        }
+        __syncthreads();                                                   // (B) t1 complete
+        // ---- out_1 and d out_1
+        f32x4 r1v[4], dv[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            r1v[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(t1 + (16 * nt + n) * HB_ROW + (32 * ks + 8 * g) * 2);
+                r1v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[ks], bf, r1v[nt], 0, 0, 0);
+            }
+            dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2T, dyb[nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                r1v[nt][r] = fmaxf(r1v[nt][r] + b1[r], 0.f);
+                dv[nt][r] = r1v[nt][r] > 0.f ? dv[nt][r] : 0.f;
+            }
+            put(t2, nt, r1v[nt]);
+            put(t3, nt, dv[nt]);
+        }
+        __syncthreads();                                                   // (C) t2, t3 complete
+        // ---- g W2 column tile w (+ g b2 on wave 0): B = r1 read transposed from t2, rows = positions
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            const unsigned char* base = t2 + (32 * k2 + 8 * g + q) * HB_ROW + (16 * w + 4 * p) * 2;
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(base + 4 * HB_ROW));
+            const s16x8 vv = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            acc_w2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dya[k2], __builtin_bit_cast(bf16x8, vv), acc_w2, 0, 0, 0);
+            if (w == 0) acc_b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dya[k2], __builtin_bit_cast(bf16x8, ones), acc_b2, 0, 0, 0);
+        }
+        // ---- d skip = [s1 > 0] . W1^T d out_1
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(t3 + (16 * nt + n) * HB_ROW + (32 * ks + 8 * g) * 2);
+                kv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1T[ks], bf, kv, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) kv[r] = s1v[nt][r] > 0.f ? kv[r] : 0.f;
+            put(t4, nt, kv);
+        }
+        __syncthreads();                                                   // (D) t4 complete
+        // ---- s1, d out_1, d skip -> HBM, whole 256-byte rows
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const int which = i >> 1, e = tid + HB_THREADS * (i & 1), pos = e >> 4, ch = e & 15;     // 1024 chunks per tile
+            const unsigned char* tl = which == 0 ? t1 : which == 1 ? t3 : t4;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(tl + pos * HB_ROW + ch * 16);
+            const int t = t0 + pos;
+            __builtin_amdgcn_raw_buffer_store_b128(v, ro[which], t < a.Tp ? (unsigned)((b * a.Tp + t) * 128 + 8 * ch) * 2u : OOB, 0, 0);
+        }
+        __syncthreads();                                                   // (E) tiles free
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int no = 4 * g + r;
+        if (no < a.NO) {
+            atomicAdd(a.gP + a.y.w2 + (size_t)no * a.O1p + 16 * w + n, acc_w2[r]);
+            if (w == 0 && n == 0) atomicAdd(a.gP + a.y.b2 + no, acc_b2[r]);
+        }
+    }
 }
 
 template <int MODE>
@@ -548,25 +740,34 @@ bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames) {
     return true;
 }
 
+constexpr size_t IMG_WSK = 8 * 12 * 1024, IMG_W1 = 8 * 4 * 1024, IMG_W2T = 8 * 1024;     // fragment images, bytes
+
 size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp) {
     const size_t row = al256((size_t)B * Tp * 256);              // one [B][Tp][128] bf16 or [B][Tp][64] fp32 buffer
-    return al256((size_t)g.L * LDS_REC) + al256((size_t)(g.L + 1) * LDS_DG) + (size_t)(g.L + 3) * row;
+    return al256((size_t)g.L * LDS_REC) + al256((size_t)(g.L + 1) * LDS_DG) + IMG_WSK + 2 * IMG_W1 + IMG_W2T +
+           (size_t)(g.L + 5) * row;
 }
 
-// after the head's backward has left d skip (fp32, (B, S, Tp)): the gated layers and the input layer.  Fills dcond and the
-// wd / bd / bx / wup / cb / cv / cc sections of gpacked (zeroed by the caller).
-int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
-                       const void* hs_bf16, const float* dskip, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
-                       long Tp, hipStream_t st) {
+// The whole stack backward behind d raw: head (out_2, out_1, skip), the gated layers, the input layer.  Fills dcond and every
+// sample-rate section of gpacked (zeroed by the caller): w2 b2 w1 b1 wsk bsk wd bd bx wup cb cv cc.
+int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
+                      const void* hs_bf16, const float* grad_out, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
+                      long Tp, hipStream_t st) {
     BwArgs a;
     a.P = packed; a.y = y; a.cond = cond; a.audio = audio; a.hs = reinterpret_cast<const unsigned short*>(hs_bf16);
     unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
     const size_t row = al256((size_t)B * Tp * 256);
     unsigned short* wrec = reinterpret_cast<unsigned short*>(p); p += al256((size_t)g.L * LDS_REC);
     unsigned short* wdg = reinterpret_cast<unsigned short*>(p);  p += al256((size_t)(g.L + 1) * LDS_DG);
+    unsigned short* iwsk = reinterpret_cast<unsigned short*>(p); p += IMG_WSK;
+    unsigned short* iw1 = reinterpret_cast<unsigned short*>(p);  p += IMG_W1;
+    unsigned short* iw1t = reinterpret_cast<unsigned short*>(p); p += IMG_W1;
+    unsigned short* iw2t = reinterpret_cast<unsigned short*>(p); p += IMG_W2T;
     a.E[0] = reinterpret_cast<float*>(p); p += row;
     a.E[1] = reinterpret_cast<float*>(p); p += row;
     unsigned short* dsk = reinterpret_cast<unsigned short*>(p); p += row;
+    unsigned short* s1 = reinterpret_cast<unsigned short*>(p);  p += row;
+    unsigned short* do1 = reinterpret_cast<unsigned short*>(p); p += row;
     a.dsk = dsk;
     a.da = reinterpret_cast<unsigned short*>(p);                 // L buffers of B*Tp*256 bytes, contiguous (no padding)
     a.wrec = wrec; a.wdg = wdg;
@@ -577,8 +778,27 @@ int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed
     hipLaunchKernelGGL(pack_wrec_kernel, dim3((g.L * 8 * 4 * 512 + 255) / 256), dim3(256), 0, st, packed + y.wd, g.L, wrec);
     hipLaunchKernelGGL(pack_wdg_kernel, dim3(((g.L + 1) * 4 * 12 * 512 + 255) / 256), dim3(256), 0, st, packed + y.wd,
                        packed + y.wsk, g.L, wdg);
-    const int tiles64 = (int)((Tp + 63) / 64);
-    hipLaunchKernelGGL(dskip_tm_kernel, dim3((unsigned)(B * tiles64)), dim3(256), 0, st, dskip, dsk, (int)Tp, tiles64);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(8 * 12 * 2), dim3(256), 0, st, packed + y.wsk, g.L * g.Hp, g.S, g.L * g.H, 8, 12, iwsk);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3(8 * 4 * 2), dim3(256), 0, st, packed + y.w1, g.Sp, g.O1, g.S, 8, 4, iw1);
+    hipLaunchKernelGGL(pack_fragT_kernel, dim3(8 * 4 * 2), dim3(256), 0, st, packed + y.w1, g.Sp, g.O1, g.S, 8, 4, iw1t);
+    hipLaunchKernelGGL(pack_fragT_kernel, dim3(8 * 2), dim3(256), 0, st, packed + y.w2, g.O1p, g.NO, g.O1, 8, 1, iw2t);
+    // ---- head
+    {
+        HbArgs h;
+        h.P = packed; h.y = y; h.hs = a.hs; h.dY = grad_out;
+        h.wsk = iwsk; h.w1 = iw1; h.w1t = iw1t; h.w2t = iw2t;
+        h.s1 = s1; h.do1 = do1; h.dsk = dsk; h.gP = gpacked;
+        h.B = B; h.Tp = (int)Tp; h.NO = g.NO; h.O1p = g.O1p;
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bl6_head_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    HB_LDS) != hipSuccess) return SWN_E_LAUNCH;
+            attr_done = true;
+        }
+        const int n_tiles = B * (int)((Tp + HB_TN - 1) / HB_TN);
+        hipLaunchKernelGGL(bl6_head_bwd_kernel, dim3(n_tiles < 256 ? n_tiles : 256), dim3(HB_THREADS), HB_LDS, st, h, n_tiles);
+    }
+    // ---- gated layers, input layer
     const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;               // frame units per utterance
     const int n_units = B * Fu;
     const int wpw = BW_THREADS / 64;
@@ -590,8 +810,24 @@ int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed
     }
     if (rc == SWN_OK) rc = launch_layer<2>(a, -1, 1, g.dil[0], n_units, Fu, grid, st);
     if (rc != SWN_OK) return rc;
-    const int tiles_per_b = (int)((Tp + 31) / 32), n_tiles = B * tiles_per_b;
-    const int split = n_tiles < 128 ? n_tiles : 128;
-    hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split, g.L), dim3(256), 0, st, a, tiles_per_b, n_tiles);
+    // ---- weight gradients: L dil_h jobs, L/2 out_skip column blocks, out_1
+    {
+        WgArgs wa;
+        wa.B = B; wa.Tp = (int)Tp;
+        const size_t lstride = (size_t)B * Tp * H;
+        int nj = 0;
+        for (int l = 0; l < g.L; ++l) {
+            const unsigned short* hl = a.hs + (size_t)l * lstride;
+            wa.job[nj++] = WJob{a.da + (size_t)l * lstride * 2, hl, hl, H, H, g.dil[l], 0, gpacked + y.wd + (size_t)l * 128 * 128, 128,
+                                gpacked + y.bd + (size_t)l * 128};
+        }
+        for (int qq = 0; qq < g.L / 2; ++qq)
+            wa.job[nj++] = WJob{dsk, a.hs + (size_t)(2 * qq + 1) * lstride, a.hs + (size_t)(2 * qq + 2) * lstride, H, H, 0, 0,
+                                gpacked + y.wsk + 128 * qq, g.L * g.Hp, qq == 0 ? gpacked + y.bsk : nullptr};
+        wa.job[nj++] = WJob{do1, s1, s1 + H, 128, 128, 0, 0, gpacked + y.w1, g.Sp, gpacked + y.b1};
+        const int tiles_per_b = (int)((Tp + 31) / 32), n_tiles = B * tiles_per_b;
+        const int split = n_tiles < 96 ? n_tiles : 96;
+        hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split, nj), dim3(256), 0, st, wa, tiles_per_b, n_tiles);
+    }
     return swn_launch_status("swn_backward_bf16");
 }

@@ -1047,14 +1047,14 @@ int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* pac
 // fused per-layer backward of the BL6 class in the mixed-precision mode (csrc/swn_bwd_bl6.hip)
 bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames);
 size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp);
-int swn_bl6_bwd_layers(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
-                       const void* hs_bf16, const float* dskip, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
-                       long Tp, hipStream_t st);
+int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
+                      const void* hs_bf16, const float* grad_out, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
+                      long Tp, hipStream_t st);
 
 namespace {
 
-// hs_bf16 != null: the gated layers run through swn_bl6_bwd_layers (the caller has checked swn_bl6_bwd_supported and
-// appended swn_bl6_bwd_scratch_bytes to `work`)
+// hs_bf16 != null: everything at sample rate runs through swn_bl6_bwd_stack (csrc/swn_bwd_bl6.hip; the caller has checked
+// swn_bl6_bwd_supported); `work` is then [dcond | front-end gradients | swn_bl6_bwd_scratch_bytes] and fwd_work is not read
 int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
                   const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
                   const float* drop_x, const float* const* drop_h,
@@ -1065,7 +1065,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     if (rc < 0) return rc;
     const SwnGeom& g = ga.g;
     const bool drop = drop_x != nullptr;
-    if (!packed || !aux || (!drop && !cond) || (drop && !drop_h) || !fe_work || !audio || !fwd_work || !grad_out || !work ||
+    if (!packed || !aux || (!drop && !cond) || (drop && !drop_h) || !fe_work || !audio || (!fwd_work && !hs_bf16) || !grad_out || !work ||
         !gpacked || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
     if (g.Hp != g.H || g.K > 8 || g.U > 256) return SWN_E_UNSUPPORTED;
     swn_make_layout(&ga.g, &ga.y);
@@ -1106,12 +1106,18 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const float* xm = r1 + r64((size_t)B * O1 * Tp);
     const float* gx = xm + r64((size_t)B * g.A0 * Tx);
     float* dxm = dfe + r64(fe_tot * B * n_frames);
+    if (hs_bf16) {                                     // compact layout: none of the fp32 sample-rate scratch exists
+        dcond = work;
+        dfe = dcond + r64((size_t)B * n_frames * g.N);
+        dxm = dfe + r64(fe_tot * B * n_frames);
+    }
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
     if (!hs_bf16 && hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     const long hsb = (long)(L + 1) * H * Tp;
 
     // ---- head: out_2, out_1, skip
+    if (!hs_bf16) {
     {   // do1 = relu'(r1) . W2^T dY ; gW2 += dY r1^T
         TimeGemm t = {packed + y.w2, 1, 0, g.O1p, grad_out, (long)NO * Tp, Tp, 1, do1, (long)O1 * Tp, Tp, r1, (long)O1 * Tp, Tp,
                       O1, 1, NO, Tp, 1, 0, 1, 0};
@@ -1131,10 +1137,11 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     {   // dh_l (skip part) = Wsk_l^T dskip for all l at once ; gWsk += dskip hcat^T
         TimeGemm t = {packed + y.wsk, 1, 0, (long)L * g.Hp, dskip, (long)S * Tp, Tp, 1, dhs + (size_t)H * Tp, hsb, Tp, nullptr, 0, 0,
                       L * H, 1, S, Tp, 1, 0, 1, 0};
-        if (!hs_bf16) launch_time(t, B, st);            // fused layer path: folded into the layer kernels' d h GEMM
+        launch_time(t, B, st);
         ReduceGemm r = {dskip, (long)S * Tp, Tp, 1, hs + (size_t)H * Tp, hsb, Tp, 1, gpacked + y.wsk, (long)L * g.Hp, 0, 1, gpacked + y.bsk,
                         S, 1, L * H, Tp, 1, 0, 1, 0};
         launch_reduce(r, B, st);
+    }
     }
     ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx;
     ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
@@ -1143,8 +1150,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     // ---- layers, last to first
     if (hs_bf16) {
         if (drop || !swn_bl6_bwd_supported(g, B, Tp, n_frames)) return SWN_E_UNSUPPORTED;
-        const int rcl = swn_bl6_bwd_layers(g, y, packed, cond, reinterpret_cast<const float*>(audio), hs_bf16, dskip, dcond, gpacked, dxm,
-                                           B, n_frames, Tp, st);
+        const int rcl = swn_bl6_bwd_stack(g, y, packed, cond, reinterpret_cast<const float*>(audio), hs_bf16, grad_out, dcond, gpacked,
+                                          dxm, B, n_frames, Tp, st);
         if (rcl < 0) return rcl;
     }
     for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
@@ -1260,8 +1267,8 @@ extern "C" size_t swn_backward_bf16_work_floats(const swn_net_desc* d, int batch
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
     if (g.kind != SWN_KIND_LAPLACE || Tp < 1 || !swn_bl6_bwd_supported(g, batch, Tp, n_frames)) return 0;
-    const size_t base = swn_backward_work_floats(d, batch, n_frames);
-    return base ? base + r64((swn_bl6_bwd_scratch_bytes(g, batch, Tp) + 3) / 4) : 0;
+    size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
+    return r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) + r64((swn_bl6_bwd_scratch_bytes(g, batch, Tp) + 3) / 4);
 }
 
 extern "C" int swn_backward_bf16(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,

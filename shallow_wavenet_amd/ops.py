@@ -348,10 +348,11 @@ def _(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc):
 
 @custom_op("swn::stack_backward_bf16", mutates_args=())
 def stack_backward_bf16(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
-                        audio: torch.Tensor, fwd_work: torch.Tensor, work_bf16: torch.Tensor, grad_raw: torch.Tensor,
+                        audio: torch.Tensor, work_bf16: torch.Tensor, grad_raw: torch.Tensor,
                         desc: List[int]) -> torch.Tensor:
-    """stack_backward after a bf16 forward of the BL6 class, gated layers fused per layer (swn_backward_bf16); raises
-    where swn_backward_bf16_work_floats() is 0 (callers check `backward_bf16_supported` first)."""
+    """stack_backward after a bf16 forward of the BL6 class with the sample-rate part fused (swn_backward_bf16): reads
+    the bf16 work buffer of the forward directly; raises where swn_backward_bf16_work_floats() is 0 (callers check
+    `backward_bf16_supported` first)."""
     Lb = _lib.lib()
     d = _desc(desc)
     dev = packed.device
@@ -364,14 +365,14 @@ def stack_backward_bf16(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Ten
     work = torch.empty(n, dtype=torch.float32, device=dev)
     gp = torch.empty_like(packed)
     with torch.cuda.device(dev):
-        _lib.check(Lb.swn_backward_bf16(r, _ptr(packed), _ptr(aux), _ptr(cond), _ptr(fe_work), _ptr(audio), _ptr(fwd_work),
+        _lib.check(Lb.swn_backward_bf16(r, _ptr(packed), _ptr(aux), _ptr(cond), _ptr(fe_work), _ptr(audio), _ptr(None),
                                         _ptr(work_bf16), _ptr(grad_raw), B, Tf, _ptr(work), _ptr(gp), _stream(dev)),
                    "backward_bf16")
     return gp
 
 
 @stack_backward_bf16.register_fake
-def _(packed, aux, cond, fe_work, audio, fwd_work, work_bf16, grad_raw, desc):
+def _(packed, aux, cond, fe_work, audio, work_bf16, grad_raw, desc):
     return torch.empty_like(packed)
 
 

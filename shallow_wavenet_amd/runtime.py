@@ -221,18 +221,18 @@ class HipNet:
         Tp = T - 1 if soft else T - 2 * cfg.seg + 1
         audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
         if self.lib.swn_train_get_precision() == 1:
-            d = ctypes.byref(self.desc)
-            work = torch.empty(self.lib.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-            res = self._bf16_train_forward(cond, audio, B, Tf, work)
+            res = self._bf16_train_forward(cond, audio, B, Tf)
             if res is not None:
-                out, wb = res
+                out, wb, work = res
                 return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, work_bf16=wb, B=B, Tf=Tf)
         out, work, _ = _O.stack_forward(self.packed, cond, audio, self.dlist, False)
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
 
-    def _bf16_train_forward(self, cond, audio, B, Tf, work):
-        """mixed-precision mode: bf16 forward, then its bf16 activations expanded into the fp32 buffers swn_backward
-        reads.  Returns None (caller runs the fp32 forward) where the library has no bf16 stack for the geometry.
+    def _bf16_train_forward(self, cond, audio, B, Tf):
+        """mixed-precision mode: bf16 forward -> (raw, bf16 work buffer, fp32 work buffer or None).  Returns None (caller
+        runs the fp32 forward) where the library has no bf16 stack for the geometry.  The fp32 expansion of the bf16
+        activations (what swn_backward reads) is skipped where the backward will read the bf16 buffer itself
+        (swn_backward_bf16, BL6 class); `backward` makes it on demand if that choice is revoked in between.
         The bf16 copy of the weights follows `packed_version` (bumped whenever the parameters were re-packed)."""
         L = self.lib
         d = ctypes.byref(self.desc)
@@ -252,8 +252,17 @@ class HipNet:
                 self._wbf16_version = self.packed_version
             _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
                                           _ptr(wb), _ptr(out), st), "forward_bf16")
-            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), st), "bf16_work_to_f32")
-        return out, wb
+        fused = self.fused_backward and _ops.backward_bf16_supported(self.dlist, B, Tf)
+        return out, wb, (None if fused else self._expand_bf16_work(wb, B, Tf))
+
+    def _expand_bf16_work(self, wb, B, Tf):
+        """bf16 work buffer of swn_forward_bf16 -> the fp32 work layout swn_backward reads (swn_bf16_work_to_f32)."""
+        L, d = self.lib, ctypes.byref(self.desc)
+        work = torch.empty(L.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), _stream_ptr(self.device)),
+                       "bf16_work_to_f32")
+        return work
 
     def _drop_args(self, drop):
         drop_x, drop_h = drop
@@ -309,7 +318,9 @@ class HipNet:
                 and _ops.backward_bf16_supported(self.dlist, B, Tf)):
             # BL6 class after a bf16 forward: the gated layers' backward fused per layer (csrc/swn_bwd_bl6.hip)
             return _O.stack_backward_bf16(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
-                                          saved["work"], wb, grad_raw, self.dlist)
+                                          wb, grad_raw, self.dlist)
+        if saved["work"] is None:                      # the forward counted on the fused backward
+            saved["work"] = self._expand_bf16_work(wb, B, Tf)
         return _O.stack_backward(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
                                  saved["work"], grad_raw, self.dlist)
 
