@@ -113,7 +113,7 @@ def unfold_packed_grads_device(net: HipNet, gp: torch.Tensor, params, want) -> L
     for p, sz in zip(params, sizes):
         if sz:
             gptr.append(base + 4 * off)
-            out.append(flat[off:off + sz].view(p.shape))
+            out.append(flat.as_strided(p.shape, p.stride(), off))        # parameters are contiguous (checked by the caller)
             off += sz
         else:
             gptr.append(None)
@@ -158,7 +158,10 @@ class LaplaceHeadFunction(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, raw, clip):
-        mu, b, logb, a, bc, lc, flag = net.laplace_head(raw, clip=clip)
+        from .. import ops as _ops                       # the implementation, not the dispatcher (see ops.py)
+        mu, b, logb, a, bc, lc, flag = _ops.laplace_head_impl(raw, net.dlist, bool(clip))
+        a = a if net.cfg.lpc > 0 else None
+        bc, lc = (bc, lc) if clip else (None, None)
         ctx.net = net
         ctx.save_for_backward(raw)
         ctx.mark_non_differentiable(flag)

@@ -1,5 +1,9 @@
 """PyTorch custom ops over the C ABI: `torch.ops.swn.*` (one `torch.library` namespace).
 
+(Each op NAME is registered from a plain function NAME_impl; the training autograd Functions of nets/_autograd.py call
+the _impl functions directly - they already sit inside an autograd node, and a Python custom op costs 30-50 us of
+dispatch per call, which the BL6 training step notices.)
+
 Every op is a thin, stateless wrapper of one entry point of `include/swn_hip.h`: it takes contiguous device tensors
 plus the network descriptor as a list of 16 integers (the fields of `swn_net_desc`, i.e. the reference constructor
 arguments), allocates its outputs with torch, and launches on torch's current HIP stream.  Failures of the library
@@ -37,10 +41,35 @@ def desc_list(cfg: NetConfig) -> List[int]:
     return [int(getattr(d, f)) for f in DESC_FIELDS]
 
 
+_DESC_CACHE: dict = {}
+
+
 def _desc(vals: Sequence[int]) -> "_lib.NetDesc":
-    if len(vals) != len(DESC_FIELDS):
-        raise RuntimeError(f"descriptor needs {len(DESC_FIELDS)} integers ({', '.join(DESC_FIELDS)})")
-    return _lib.NetDesc(**{f: int(v) for f, v in zip(DESC_FIELDS, vals)})
+    key = tuple(vals)
+    d = _DESC_CACHE.get(key)
+    if d is None:
+        if len(vals) != len(DESC_FIELDS):
+            raise RuntimeError(f"descriptor needs {len(DESC_FIELDS)} integers ({', '.join(DESC_FIELDS)})")
+        d = _DESC_CACHE[key] = _lib.NetDesc(**{f: int(v) for f, v in zip(DESC_FIELDS, vals)})
+    return d
+
+
+class _on:
+    """`with _on(dev):` = torch.cuda.device(dev) only when dev is not the current device (the context manager costs
+    more host time than a launch)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if dev.index is None or dev.index == torch.cuda.current_device() else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            return self.ctx.__exit__(*exc)
+        return False
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -66,8 +95,7 @@ def _need_cuda(t: torch.Tensor, what: str) -> None:
 
 
 # ------------------------------------------------------------------------------------------ pack
-@custom_op("swn::pack_params", mutates_args=())
-def pack_params(tensors: List[torch.Tensor], desc: List[int]) -> torch.Tensor:
+def pack_params_impl(tensors: List[torch.Tensor], desc: List[int]) -> torch.Tensor:
     """state_dict tensors (reference order, on the device) -> packed buffer (swn_pack_params_device)."""
     L = _lib.lib()
     d = _desc(desc)
@@ -77,10 +105,13 @@ def pack_params(tensors: List[torch.Tensor], desc: List[int]) -> torch.Tensor:
     total = L.swn_packed_floats(ctypes.byref(d))
     out = torch.empty(total, dtype=torch.float32, device=dev)
     ptrs = (ctypes.c_void_p * len(keep))(*[t.data_ptr() for t in keep])
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.swn_pack_params_device(ctypes.byref(d), ptrs, len(keep), _ptr(out), total, _stream(dev)),
                    "pack_params_device")
     return out
+
+
+pack_params = custom_op("swn::pack_params", mutates_args=())(pack_params_impl)
 
 
 @pack_params.register_fake
@@ -90,8 +121,7 @@ def _(tensors, desc):
 
 
 # ------------------------------------------------------------------------------------------ front end
-@custom_op("swn::frontend", mutates_args=())
-def frontend(packed: torch.Tensor, aux: torch.Tensor, desc: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
+def frontend_impl(packed: torch.Tensor, aux: torch.Tensor, desc: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
     """aux (B, n_aux, Tf) -> cond (B, Tf, L*seg*2H) and the work buffer the backward needs (swn_frontend)."""
     L = _lib.lib()
     d = _desc(desc)
@@ -104,9 +134,12 @@ def frontend(packed: torch.Tensor, aux: torch.Tensor, desc: List[int]) -> Tuple[
     r = ctypes.byref(d)
     work = torch.empty(L.swn_frontend_work_floats(r, B, Tf), dtype=torch.float32, device=dev)
     cond = torch.empty(L.swn_cond_floats(r, B, Tf), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.swn_frontend(r, _ptr(packed), _ptr(aux), B, Tf, _ptr(work), _ptr(cond), _stream(dev)), "frontend")
     return cond.view(B, Tf, -1), work
+
+
+frontend = custom_op("swn::frontend", mutates_args=())(frontend_impl)
 
 
 @frontend.register_fake
@@ -119,8 +152,7 @@ def _(packed, aux, desc):
 
 
 # ------------------------------------------------------------------------------------------ decode
-@custom_op("swn::decode", mutates_args=())
-def decode(packed: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor], forced: Optional[torch.Tensor],
+def decode_impl(packed: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor], forced: Optional[torch.Tensor],
            seed: Optional[torch.Tensor], desc: List[int], n_steps: int, variant: int, rng_seed: int, rng_utt0: int,
            want_heads: bool, want_noise: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """prologue + n_steps generation steps for every utterance (swn_decode).  noise None = drawn in the kernels."""
@@ -152,10 +184,13 @@ def decode(packed: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tenso
     io = _lib.DecodeIO(noise_dev=_ptr(noise), forced_dev=_ptr(forced), seed_dev=_ptr(seed),
                        noise_out_dev=_ptr(used if want_noise else None),
                        rng_seed=int(rng_seed) & 0xFFFFFFFFFFFFFFFF, rng_utt0=int(rng_utt0) & 0xFFFFFFFF, reserved=0)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(L.swn_decode(r, _ptr(packed), _ptr(cond), B, Tf, n_steps, ctypes.byref(io), _ptr(state), _ptr(out),
                                 _ptr(heads if want_heads else None), variant, _stream(dev)), "decode")
     return out, heads, used
+
+
+decode = custom_op("swn::decode", mutates_args=())(decode_impl)
 
 
 @decode.register_fake
@@ -176,8 +211,7 @@ def _tp(d, Tf: int) -> Tuple[int, int]:
     return T, (T - 1 if soft else T - 2 * seg + 1)
 
 
-@custom_op("swn::stack_forward", mutates_args=())
-def stack_forward(packed: torch.Tensor, cond: torch.Tensor, audio: torch.Tensor, desc: List[int],
+def stack_forward_impl(packed: torch.Tensor, cond: torch.Tensor, audio: torch.Tensor, desc: List[int],
                   want_hidden: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """raw out_2 outputs (B, n_out, Tp) of the fp32 parity kernels, the work buffer swn_backward reads, and
     optionally the hidden states (B, L+1, H, Tp) (swn_forward)."""
@@ -195,10 +229,13 @@ def stack_forward(packed: torch.Tensor, cond: torch.Tensor, audio: torch.Tensor,
     work = torch.empty(Lb.swn_forward_work_floats(r, B, Tf), dtype=torch.float32, device=dev)
     out = torch.empty((B, n_out, Tp), dtype=torch.float32, device=dev)
     hs = torch.empty((B, L + 1, H, Tp) if want_hidden else (0,), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(Lb.swn_forward(r, _ptr(packed), _ptr(cond.contiguous()), _ptr(audio), B, Tf, _ptr(work), _ptr(out),
                                   _ptr(hs if want_hidden else None), _stream(dev)), "forward")
     return out, work, hs
+
+
+stack_forward = custom_op("swn::stack_forward", mutates_args=())(stack_forward_impl)
 
 
 @stack_forward.register_fake
@@ -211,8 +248,7 @@ def _(packed, cond, audio, desc, want_hidden):
             packed.new_empty((B, L + 1, H, Tp) if want_hidden else (0,)))
 
 
-@custom_op("swn::pack_bf16", mutates_args=())
-def pack_bf16(packed: torch.Tensor, desc: List[int]) -> torch.Tensor:
+def pack_bf16_impl(packed: torch.Tensor, desc: List[int]) -> torch.Tensor:
     """bf16 weight images of the MFMA stacks (swn_pack_bf16); raises where the geometry has no bf16 stack."""
     Lb = _lib.lib()
     d = _desc(desc)
@@ -227,14 +263,16 @@ def pack_bf16(packed: torch.Tensor, desc: List[int]) -> torch.Tensor:
     return w
 
 
+pack_bf16 = custom_op("swn::pack_bf16", mutates_args=())(pack_bf16_impl)
+
+
 @pack_bf16.register_fake
 def _(packed, desc):
     d = _desc(desc)
     return packed.new_empty(_lib.lib().swn_bf16_weight_bytes(ctypes.byref(d)), dtype=torch.uint8)
 
 
-@custom_op("swn::stack_forward_bf16", mutates_args=())
-def stack_forward_bf16(packed: torch.Tensor, wbf16: torch.Tensor, cond: torch.Tensor, audio: torch.Tensor,
+def stack_forward_bf16_impl(packed: torch.Tensor, wbf16: torch.Tensor, cond: torch.Tensor, audio: torch.Tensor,
                        desc: List[int]) -> Tuple[torch.Tensor, torch.Tensor]:
     """bf16 MFMA variant of stack_forward: raw (B, n_out, Tp) fp32 and the bf16 work buffer (swn_forward_bf16)."""
     Lb = _lib.lib()
@@ -250,10 +288,13 @@ def stack_forward_bf16(packed: torch.Tensor, wbf16: torch.Tensor, cond: torch.Te
     r = ctypes.byref(d)
     work = torch.empty(Lb.swn_forward_bf16_work_bytes(r, B, Tf), dtype=torch.uint8, device=dev)
     out = torch.empty((B, n_out, Tp), dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(Lb.swn_forward_bf16(r, _ptr(packed), _ptr(wbf16), _ptr(cond.contiguous()), _ptr(audio), B, Tf,
                                        _ptr(work), _ptr(out), _stream(dev)), "forward_bf16")
     return out, work
+
+
+stack_forward_bf16 = custom_op("swn::stack_forward_bf16", mutates_args=())(stack_forward_bf16_impl)
 
 
 @stack_forward_bf16.register_fake
@@ -267,8 +308,7 @@ def _(packed, wbf16, cond, audio, desc):
 
 
 # ------------------------------------------------------------------------------------------ Laplace head
-@custom_op("swn::laplace_head", mutates_args=())
-def laplace_head(raw: torch.Tensor, desc: List[int], clip: bool
+def laplace_head_impl(raw: torch.Tensor, desc: List[int], clip: bool
                  ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """raw (B, n_out, Tp) -> mu, b, logb, a, b_clip, logb_clip (time-major; empty where not produced), below_floor."""
     Lb = _lib.lib()
@@ -282,11 +322,14 @@ def laplace_head(raw: torch.Tensor, desc: List[int], clip: bool
     a = mk(lpc, lpc > 0)
     bc, lc = mk(seg, clip), mk(seg, clip)
     flag = torch.zeros(1, dtype=torch.int32, device=dev)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(Lb.swn_laplace_head(ctypes.byref(d), _ptr(raw.contiguous()), B, Tp, _ptr(mu), _ptr(b), _ptr(logb),
                                        _ptr(a if lpc > 0 else None), _ptr(bc if clip else None),
                                        _ptr(lc if clip else None), _ptr(flag), _stream(dev)), "laplace_head")
     return mu, b, logb, a, bc, lc, flag
+
+
+laplace_head = custom_op("swn::laplace_head", mutates_args=())(laplace_head_impl)
 
 
 @laplace_head.register_fake
@@ -298,8 +341,7 @@ def _(raw, desc, clip):
             raw.new_empty(1, dtype=torch.int32))
 
 
-@custom_op("swn::laplace_head_backward", mutates_args=())
-def laplace_head_backward(raw: torch.Tensor, gmu: Optional[torch.Tensor], gb: Optional[torch.Tensor],
+def laplace_head_backward_impl(raw: torch.Tensor, gmu: Optional[torch.Tensor], gb: Optional[torch.Tensor],
                           glogb: Optional[torch.Tensor], ga: Optional[torch.Tensor], gb_clip: Optional[torch.Tensor],
                           glogb_clip: Optional[torch.Tensor], desc: List[int]) -> torch.Tensor:
     Lb = _lib.lib()
@@ -310,11 +352,14 @@ def laplace_head_backward(raw: torch.Tensor, gmu: Optional[torch.Tensor], gb: Op
     gmu, gb, glogb, ga, gb_clip, glogb_clip = c(gmu), c(gb), c(glogb), c(ga), c(gb_clip), c(glogb_clip)
     raw = raw.contiguous()
     graw = torch.empty_like(raw)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(Lb.swn_laplace_head_backward(ctypes.byref(d), _ptr(raw), B, Tp, _ptr(gmu), _ptr(gb), _ptr(glogb),
                                                 _ptr(ga), _ptr(gb_clip), _ptr(glogb_clip), _ptr(graw), _stream(dev)),
                    "laplace_head_backward")
     return graw
+
+
+laplace_head_backward = custom_op("swn::laplace_head_backward", mutates_args=())(laplace_head_backward_impl)
 
 
 @laplace_head_backward.register_fake
@@ -323,8 +368,7 @@ def _(raw, gmu, gb, glogb, ga, gb_clip, glogb_clip, desc):
 
 
 # ------------------------------------------------------------------------------------------ backward of the stack
-@custom_op("swn::stack_backward", mutates_args=())
-def stack_backward(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
+def stack_backward_impl(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
                    audio: torch.Tensor, fwd_work: torch.Tensor, grad_raw: torch.Tensor, desc: List[int]) -> torch.Tensor:
     """gradient of the loss wrt the packed parameter buffer given d loss / d raw (swn_backward)."""
     Lb = _lib.lib()
@@ -335,10 +379,13 @@ def stack_backward(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, 
     grad_raw = grad_raw.to(dev, torch.float32).contiguous()
     work = torch.empty(Lb.swn_backward_work_floats(r, B, Tf), dtype=torch.float32, device=dev)
     gp = torch.empty_like(packed)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(Lb.swn_backward(r, _ptr(packed), _ptr(aux), _ptr(cond), _ptr(fe_work), _ptr(audio), _ptr(fwd_work),
                                    _ptr(None), _ptr(grad_raw), B, Tf, _ptr(work), _ptr(gp), _stream(dev)), "backward")
     return gp
+
+
+stack_backward = custom_op("swn::stack_backward", mutates_args=())(stack_backward_impl)
 
 
 @stack_backward.register_fake
@@ -346,8 +393,7 @@ def _(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc):
     return torch.empty_like(packed)
 
 
-@custom_op("swn::stack_backward_bf16", mutates_args=())
-def stack_backward_bf16(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
+def stack_backward_bf16_impl(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
                         audio: torch.Tensor, work_bf16: torch.Tensor, grad_raw: torch.Tensor,
                         desc: List[int]) -> torch.Tensor:
     """stack_backward after a bf16 forward of the BL6 class with the sample-rate part fused (swn_backward_bf16): reads
@@ -364,11 +410,14 @@ def stack_backward_bf16(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Ten
     grad_raw = grad_raw.to(dev, torch.float32).contiguous()
     work = torch.empty(n, dtype=torch.float32, device=dev)
     gp = torch.empty_like(packed)
-    with torch.cuda.device(dev):
+    with _on(dev):
         _lib.check(Lb.swn_backward_bf16(r, _ptr(packed), _ptr(aux), _ptr(cond), _ptr(fe_work), _ptr(audio), _ptr(None),
                                         _ptr(work_bf16), _ptr(grad_raw), B, Tf, _ptr(work), _ptr(gp), _stream(dev)),
                    "backward_bf16")
     return gp
+
+
+stack_backward_bf16 = custom_op("swn::stack_backward_bf16", mutates_args=())(stack_backward_bf16_impl)
 
 
 @stack_backward_bf16.register_fake

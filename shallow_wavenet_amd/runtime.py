@@ -213,8 +213,7 @@ class HipNet:
             return self._forward_train_drop(aux, audio, drop)
         cfg = self.cfg
         aux = aux.to(self.device, torch.float32).contiguous()
-        cond = self.frontend(aux)
-        fe_work = self._last_frontend_work
+        cond, fe_work = _ops.frontend_impl(self.packed, aux, self.dlist)
         soft = cfg.kind == "softmax"
         B, Tf = cond.shape[0], cond.shape[1]
         T = Tf * cfg.U
@@ -245,7 +244,7 @@ class HipNet:
         soft = self.cfg.kind == "softmax"
         Tp = Tf * self.cfg.U - 1 if soft else Tf * self.cfg.U - 2 * self.cfg.seg + 1
         out = torch.empty((B, self.cfg.n_out, Tp), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _ops._on(self.device):
             st = _stream_ptr(self.device)
             if getattr(self, "_wbf16_version", -1) != self.packed_version:
                 _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), st), "pack_bf16")
@@ -259,7 +258,7 @@ class HipNet:
         """bf16 work buffer of swn_forward_bf16 -> the fp32 work layout swn_backward reads (swn_bf16_work_to_f32)."""
         L, d = self.lib, ctypes.byref(self.desc)
         work = torch.empty(L.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _ops._on(self.device):
             _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), _stream_ptr(self.device)),
                        "bf16_work_to_f32")
         return work
@@ -291,7 +290,7 @@ class HipNet:
         d = ctypes.byref(self.desc)
         work = torch.empty(self.lib.swn_forward_drop_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
         out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
-        with torch.cuda.device(self.device):
+        with _ops._on(self.device):
             _lib.check(self.lib.swn_forward_drop(d, _ptr(self.packed), _ptr(fe_work), _ptr(audio), B, Tf, _ptr(drop_x),
                                                  ctypes.cast(ptrs, ctypes.c_void_p), _ptr(work), _ptr(out), _ptr(None),
                                                  _stream_ptr(self.device)), "forward_drop")
@@ -307,7 +306,7 @@ class HipNet:
             drop_x, drop_h, ptrs = saved["drop"]
             work = torch.empty(L.swn_backward_drop_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
             gp = torch.empty_like(self.packed)
-            with torch.cuda.device(self.device):
+            with _ops._on(self.device):
                 _lib.check(L.swn_backward_drop(d, _ptr(self.packed), _ptr(saved["aux"]), _ptr(saved["fe_work"]),
                                                _ptr(saved["audio"]), _ptr(saved["work"]), _ptr(None), _ptr(drop_x),
                                                ctypes.cast(ptrs, ctypes.c_void_p), _ptr(grad_raw), B, Tf, _ptr(work),
@@ -317,12 +316,12 @@ class HipNet:
         if (wb is not None and self.fused_backward and L.swn_train_get_precision() == 1
                 and _ops.backward_bf16_supported(self.dlist, B, Tf)):
             # BL6 class after a bf16 forward: the gated layers' backward fused per layer (csrc/swn_bwd_bl6.hip)
-            return _O.stack_backward_bf16(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
-                                          wb, grad_raw, self.dlist)
+            return _ops.stack_backward_bf16_impl(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
+                                                 wb, grad_raw, self.dlist)
         if saved["work"] is None:                      # the forward counted on the fused backward
             saved["work"] = self._expand_bf16_work(wb, B, Tf)
-        return _O.stack_backward(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
-                                 saved["work"], grad_raw, self.dlist)
+        return _ops.stack_backward_impl(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
+                                        saved["work"], grad_raw, self.dlist)
 
     def laplace_head_backward(self, raw, gmu, gb, glogb, ga, gb_clip=None, glogb_clip=None) -> torch.Tensor:
-        return _O.laplace_head_backward(raw, gmu, gb, glogb, ga, gb_clip, glogb_clip, self.dlist)
+        return _ops.laplace_head_backward_impl(raw, gmu, gb, glogb, ga, gb_clip, glogb_clip, self.dlist)

@@ -22,6 +22,17 @@ for p in m.scale_in.parameters():
     p.requires_grad = False
 opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
 acc = {}
+from shallow_wavenet_amd.nets import _autograd as _ag
+from shallow_wavenet_amd.runtime import HipNet
+def _wrap(owner, name, label):
+    f = getattr(owner, name)
+    def g(*a, **k):
+        t0 = time.perf_counter(); r = f(*a, **k); tick(label, t0); return r
+    setattr(owner, name, g)
+_wrap(_ag, "unfold_packed_grads_device", "  bwd.unfold")
+_wrap(HipNet, "backward", "  bwd.stack")
+_wrap(HipNet, "laplace_head_backward", "  bwd.head")
+_wrap(HipNet, "forward_train", "  fwd.stack")
 def tick(name, t0):
     acc[name] = acc.get(name, 0.0) + time.perf_counter() - t0
 def step():
