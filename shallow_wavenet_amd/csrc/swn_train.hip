@@ -737,7 +737,11 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     // workgroup = (64 in_x rows, frame f, utterance b).  The U + seg - 1 positions the frame touches are staged
     // through LDS with coalesced loads (lanes along t; it used to be one strided stream per thread, thrashing L1),
     // then one thread per row does its U x seg multiply-adds out of LDS (row pitch odd: conflict-free).
-    __shared__ float tile[64][256 + 16 + 1];
+    // pitch = the frame's U + seg - 1 columns rounded up to odd (a fixed 273-float pitch for U <= 256 held the kernel at
+    // two workgroups per CU: 182 us per layer at REF6, latency-bound)
+    extern __shared__ float tile_mem[];
+    const int pitch = (a.g.U + a.g.seg - 1) | 1;
+    auto tile = [&](int r, int c) -> float& { return tile_mem[r * pitch + c]; };
     __shared__ float wus[256];
     __shared__ float cs[10][64];                 // seg <= 10 (swn_make_geom)
     const SwnGeom& g = a.g;
@@ -761,7 +765,7 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
                 v[i] = bld1(rD, (tok && o2 < H2) ? (unsigned)(((size_t)o2 * a.Tp + t) * 4) : SWN_OOB);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) tile[w + 4 * i][c] = v[i];
+            for (int i = 0; i < 16; ++i) tile(w + 4 * i, c) = v[i];
         }
     }
     __syncthreads();
@@ -773,7 +777,7 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
             for (int sx = 0; sx < seg; ++sx) {
                 const int c = jj + (seg - 1) - sx;
 #pragma unroll 8
-                for (int r = 0; r < 64; ++r) acc = fmaf(tile[r][c], cs[sx][r], acc);
+                for (int r = 0; r < 64; ++r) acc = fmaf(tile(r, c), cs[sx][r], acc);
             }
             atomicAdd(gwup + jj, acc);
         }
@@ -785,7 +789,7 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     for (int s = 0; s < seg; ++s) {
         float dsum = 0.f;
         for (int jj = 0; jj < U; ++jj) {
-            const float d = tile[tid][jj + (seg - 1) - s];           // t = f*U + jj - s - coff
+            const float d = tile(tid, jj + (seg - 1) - s);           // t = f*U + jj - s - coff
             dsum = fmaf(wus[jj], d, dsum);
             if (s == 0) bsum += d;                                   // every position belongs to exactly one (f, jj) at s = 0
         }
@@ -1185,7 +1189,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             launch_time(t, B, st);
         }
         if (!drop) {
-            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 63) / 64, n_frames, B), dim3(256), 0, st, ga, dcond, gpacked + y.bx,
+            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 63) / 64, n_frames, B), dim3(256),
+                               (size_t)64 * ((g.U + g.seg - 1) | 1) * sizeof(float), st, ga, dcond, gpacked + y.bx,
                                gpacked + y.wup);
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
