@@ -297,6 +297,13 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
            "includes": "forward + LaplaceLoss + backward + Adam step + parameter re-pack, wall clock"}
     peak = MFMA_BF16_TFLOPS if mode == "bf16" else MFMA_FP32_TFLOPS
     leg["roofline"] = _mfma(flops, ms, peak, kernel=kernel, algorithmic_flops="3 x forward (2 x MAC)")
+    if mode == "bf16" and cfg.H == 64 and cfg.K == 2 and cfg.seg == 1:
+        # the fused BL6 path is bound by its streams, not by the matrix cores: bytes per position of the
+        # sample-rate launches - forward 128 + 6 x 256 + 776, head backward 1 800, six layer launches x 1 408, the last
+        # launch 520, ten weight-gradient jobs x 512
+        bpp = 128 + 6 * 256 + 776 + 1800 + 6 * 1408 + 520 + 10 * 512
+        leg["roofline_hbm"] = _hbm(float(bpp) * pos, ms, kernel="bl6_layer_bwd_kernel x 7 + bl6_wgrad_kernel + bl6_head_bwd_kernel"
+                                   " + bf16 forward", algorithmic_bytes_per_position=bpp)
     return leg
 
 
@@ -310,6 +317,7 @@ def run_legs(dev, quick: bool = False):
         except Exception as e:                                  # noqa: BLE001  a leg must not cost the line
             legs[key] = {"error": f"{type(e).__name__}: {e}"}
         legs[key]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()        # a leg's cached blocks must not make the next leg's first allocations free them
 
     bl6 = C.bl6_laplace(1, 0)
     add("cfg2_caller", decode_leg, "cfg2: CSWNV BL6 seg=1 lpc=0, 22.05 kHz, 1 utterance x Tf=600, batch_fast_generate as called",
@@ -345,13 +353,15 @@ def run_legs(dev, quick: bool = False):
     add("cfg4_ref6_fwd_fp32", forward_leg, "cfg4 forward: REF6, 8 x 16 500 positions, fp32 parity kernels (exact-fp32 MFMA)", ref6, dev, 8, 150, "fp32", 2,
         "tf_layer_kernel x 6 + gemm_wx_kernel x 3")
     add("cfg4_bl6_step_bf16", train_leg, "cfg4 training step: BL6, 8 x 16 500, mixed precision", bl6, dev, 8, 150, "bf16", 5,
-        "bf16 forward + gate_bwd / time_gemm_bf16t / reduce_gemm_bf16s per layer")
+        "bf16 forward + fused backward (bl6_head_bwd / bl6_layer_bwd x 7 / bl6_wgrad) + unfold_grads")
     add("cfg4_bl6_step_fp32", train_leg, "cfg4 training step: BL6, 8 x 16 500, fp32 parity mode", bl6, dev, 8, 150, "fp32", 3,
         "tf_layer + time_gemm / reduce_gemm (exact-fp32 MFMA)")
     add("cfg4_ref6_step_bf16", train_leg, "cfg4 training step: REF6, 8 x 16 500, mixed precision", ref6, dev, 8, 150, "bf16", 3,
         "bf16g_gemm + time_gemm_bf16t / reduce_gemm_bf16s")
     add("cfg4_ref6_step_fp32", train_leg, "cfg4 training step: REF6, 8 x 16 500, fp32 parity mode", ref6, dev, 8, 150, "fp32", 2,
         "tf_layer + time_gemm / reduce_gemm (exact-fp32 MFMA)")
+    add("cfg4_bl6_step_bf16_b64", train_leg, "the same step at 8x the batch: BL6, 64 x 16 500, mixed precision", bl6, dev, 64, 150,
+        "bf16", 3, "bf16 forward + fused backward (bl6_head_bwd / bl6_layer_bwd x 7 / bl6_wgrad) + unfold_grads")
     return legs
 
 

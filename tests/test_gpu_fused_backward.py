@@ -48,7 +48,7 @@ def _run(cfg, B, Tf, seed=5):
 
 
 @pytest.mark.parametrize("lpc", [0, 2])
-@pytest.mark.parametrize("B,Tf", [(1, 2), (3, 12), (2, 33)])
+@pytest.mark.parametrize("B,Tf", [(1, 2), (3, 12), (2, 33), (8, 150), (64, 150)])   # the last two: BASELINE cfg4 and 8x its batch
 def test_fused_layers_match_the_chain(gpu_ok, B, Tf, lpc):
     cfg = C.bl6_laplace(1, lpc)
     net, g1, g0 = _run(cfg, B, Tf)
