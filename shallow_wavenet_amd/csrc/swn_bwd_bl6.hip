@@ -132,11 +132,19 @@ __global__ void pack_wdg_kernel(const float* __restrict__ wd, const float* __res
 constexpr int LDS_REC = 32768;                                 // 128 x 128 bf16 fragment image (recompute)
 constexpr int LDS_DG = 49152;                                  // 64 x 384 bf16 fragment image (data gradient | skip)
 constexpr int BW_LDS = LDS_REC + LDS_DG + 4 * (256 + 128 + 128 + 128);
-constexpr int BW_THREADS = 512;                                // 8 waves, one workgroup per CU (two waves per SIMD)
 
-template <int MODE>
-__global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwArgs a, const int l, const int dil, const int dil_up,
-                                                                      const int n_units, const int Fu) {
+// HALF: a wave owns one HALF of the channels (32 of 64: accumulator tiles 2hh, 2hh+1) of its frame, two waves per frame.
+// The work of a chunk and every per-lane accumulator halve, so twelve waves fit a CU (<= 170 registers): at BASELINE cfg4 the
+// 1 200 frames become 2 400 units for 3 072 wave slots (whole frames: 1 200 units on 150 of the 256 CUs, 71.5 us per layer;
+// halves: 68 us, against 45 at the HBM roof).  Both waves fetch all B fragments (the K axis is not split); at large batches,
+// where the launch is HBM-bound, the whole-frame form is kept - except for the last launch, whose 64 extra accumulators for
+// the input layer spill in the whole-frame form (390 -> 244 us at 64 x 16 500).
+template <bool HALF> struct BwShape { static constexpr int NM = HALF ? 2 : 4, THREADS = HALF ? 768 : 512; };
+
+template <int MODE, bool HALF>
+__global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kernel(const BwArgs a, const int l, const int dil,
+                                                                                 const int dil_up, const int n_units, const int Fu) {
+    constexpr int NM = BwShape<HALF>::NM, THREADS = BwShape<HALF>::THREADS;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* s_rec = smem;
     unsigned char* s_dg = smem + LDS_REC;
@@ -152,13 +160,13 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
         const uint4* s0 = reinterpret_cast<const uint4*>(a.wrec) + (size_t)(MODE == 2 ? 0 : l) * (LDS_REC / 16);
         const uint4* s1 = reinterpret_cast<const uint4*>(a.wdg) + (size_t)(l + 1) * (LDS_DG / 16);
         if (MODE != 2)
-            for (int e = tid; e < LDS_REC / 16; e += BW_THREADS) reinterpret_cast<uint4*>(s_rec)[e] = s0[e];
-        for (int e = tid; e < LDS_DG / 16; e += BW_THREADS) reinterpret_cast<uint4*>(s_dg)[e] = s1[e];
+            for (int e = tid; e < LDS_REC / 16; e += THREADS) reinterpret_cast<uint4*>(s_rec)[e] = s0[e];
+        for (int e = tid; e < LDS_DG / 16; e += THREADS) reinterpret_cast<uint4*>(s_dg)[e] = s1[e];
         if (MODE != 2 && tid < 256)
             cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid] : a.P[a.y.bx + (size_t)l * 128 + tid - 128];
         if (MODE == 2 && tid < 320)                // cb | cv tap 0 | cv tap 1 | cc tap 0 | cc tap 1  (overlays wus, unused here)
             cst[tid] = tid < 64 ? a.P[a.y.cb + tid] : tid < 192 ? a.P[a.y.cv + tid - 64] : a.P[a.y.cc + tid - 192];
-        if (tid >= 384) { const int i = tid - 384; if (MODE != 2) wus[i] = i < a.U ? a.P[a.y.wup + i] : 0.f; gwl[i] = 0.f; gbl[i] = 0.f; }
+        if (tid >= 384 && tid < 512) { const int i = tid - 384; if (MODE != 2) wus[i] = i < a.U ? a.P[a.y.wup + i] : 0.f; gwl[i] = 0.f; gbl[i] = 0.f; }
     }
     __syncthreads();
     const size_t lstride = (size_t)a.B * a.Tp * H;                       // one layer of hidden states, elements
@@ -174,102 +182,121 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
     const unsigned lane_e = (unsigned)(n * H + 8 * g) * 4u;              // fp32 [t][64]: channels 8g.. of position n
     const unsigned dil_bytes = (unsigned)dil * H * 2u, dilu_bytes = (unsigned)dil_up * 256u;
 
-    float gbx[2][4][4];
+    float gbx[2][NM][4];
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) gbx[q][m][r] = 0.f;
-    float inl[4][4][4];                            // MODE 2: g cb | g cv tap 0 | g cv tap 1 | g cc tap 0 of this lane's channels
+    float inl[4][NM][4];                           // MODE 2: g cb | g cv tap 0 | g cv tap 1 | g cc tap 0 of this lane's channels
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int m = 0; m < 4; ++m)
+        for (int m = 0; m < NM; ++m)
 #pragma unroll
             for (int r = 0; r < 4; ++r) inl[q][m][r] = 0.f;
 
-    const int Wn = gridDim.x * (BW_THREADS / 64);
-    for (int j = blockIdx.x * (BW_THREADS / 64) + w; j < n_units; j += Wn) {
+    const int Wn = gridDim.x * (THREADS / 64);
+    const int n_jobs = HALF ? 2 * n_units : n_units;
+    for (int jj_ = blockIdx.x * (THREADS / 64) + w; jj_ < n_jobs; jj_ += Wn) {
+        const int j = HALF ? jj_ >> 1 : jj_;
+        const int mb = HALF ? 2 * (jj_ & 1) : 0;                 // first accumulator tile of this wave: channels chan_of(mb + m, g, r)
+        const unsigned chb = (unsigned)(32 * (mb >> 1));         // = 32 hh: first channel of the wave's range (tile pairs are 32 channels)
         const int b = j / Fu, f = j - b * Fu;
         const int s = f * a.U - a.coff;
         const int ts = s > 0 ? s : 0;
         int te = s + a.U; te = te < a.Tp ? te : a.Tp;
         const int jj0 = ts - s;
-        float4 cz[4], cc[4];
+        float4 cz[NM], cc[NM];
         if (MODE != 2) {
             const int fc = f < a.Tf - 1 ? f : a.Tf - 1;
-            const unsigned off = (unsigned)((b * a.Tf + fc) * a.N + l * 128 + 8 * g) * 4u;
+            const unsigned off = (unsigned)((b * a.Tf + fc) * a.N + l * 128 + 8 * g) * 4u + chb * 4u;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                cz[q] = ld_f4(rc, off + (unsigned)(32 * (q >> 1) + 4 * (q & 1)) * 4u);
-                cc[q] = ld_f4(rc, off + (unsigned)(H + 32 * (q >> 1) + 4 * (q & 1)) * 4u);
+            for (int q = 0; q < NM; ++q) {         // tile mb + q: channels chb' + 8g + 4 (q & 1) ..
+                const unsigned co = (unsigned)(32 * (q >> 1) + 4 * (q & 1)) * 4u;
+                cz[q] = ld_f4(rc, off + co);
+                cc[q] = ld_f4(rc, off + co + H * 4u);
             }
         }
-        float dca[2][4][4];
+        float dca[2][NM][4];
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < NM; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) dca[q][m][r] = 0.f;
 
-        for (int t0 = ts; t0 < te; t0 += 16) {
+        // every load of a chunk is issued together.  (Issuing the NEXT chunk's loads ahead of the current chunk's work - eight
+        // waves, the freed registers holding them - was slower, 84 us per layer: what separates a frame's dependent chunks is
+        // not memory latency but the chunk's own chain of LDS-fed MFMAs and transcendentals, which more waves hide better.)
+        struct Loads { f32x4 D[NM]; bf16x8 du[12]; bf16x8 x[4]; float au0, au1; };
+        auto fetch = [&](const int t0, Loads& q) {
             const int t = t0 + n;
             const bool ok = t < te;
             const unsigned pos = (unsigned)(b * a.Tp + t0);
-            // ---- every load of the chunk is issued up front
-            f32x4 D[4];
-            if (MODE != 0) {                       // highway carry of the layer above: channels chan_of(m, g, 0..3)
-                const unsigned eo = ok ? pos * 256u + lane_e : OOB;
+            if (MODE != 0) {                       // highway carry of the layer above: channels chan_of(mb + m, g, 0..3)
+                const unsigned eo = ok ? pos * 256u + lane_e + chb * 4u : OOB;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
-                    D[m] = __builtin_bit_cast(f32x4, ld_u4(rei, eo + (unsigned)(32 * (m >> 1) + 4 * (m & 1)) * 4u));
+                for (int m = 0; m < NM; ++m)
+                    q.D[m] = __builtin_bit_cast(f32x4, ld_u4(rei, eo + (unsigned)(32 * (m >> 1) + 4 * (m & 1)) * 4u));
             } else {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) D[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int m = 0; m < NM; ++m) q.D[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
-            bf16x8 du[12];
             {
                 const unsigned o1 = ok ? pos * 256u + lane_d : OOB;
                 if (MODE != 0) {
                     const unsigned o0 = (ok && t + dil_up < a.Tp) ? o1 + dilu_bytes : OOB;
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) { du[ks] = ld_bf8(rdu, o0 + 64u * ks); du[4 + ks] = ld_bf8(rdu, o1 + 64u * ks); }
+                    for (int ks = 0; ks < 4; ++ks) { q.du[ks] = ld_bf8(rdu, o0 + 64u * ks); q.du[4 + ks] = ld_bf8(rdu, o1 + 64u * ks); }
                 }
                 if (MODE != 2) {
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) du[8 + ks] = ld_bf8(rsk, o1 + 64u * ks);
+                    for (int ks = 0; ks < 4; ++ks) q.du[8 + ks] = ld_bf8(rsk, o1 + 64u * ks);
                 }
             }
-            bf16x8 x[4];
-            float au0 = 0.f, au1 = 0.f;
+            q.au0 = 0.f; q.au1 = 0.f;
             if (MODE == 2) {
-                au1 = ld_f1(rau, ok ? (pos + n) * 4u : OOB);
-                au0 = ld_f1(rau, (ok && t >= 1) ? (pos + n - 1) * 4u : OOB);
+                q.au1 = ld_f1(rau, ok ? (pos + n) * 4u : OOB);
+                q.au0 = ld_f1(rau, (ok && t >= 1) ? (pos + n - 1) * 4u : OOB);
             }
             if (MODE != 2) {
                 const unsigned base = pos * (H * 2u) + lane_h;
                 const unsigned o1 = ok ? base : OOB;
                 const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
-                x[0] = ld_bf8(rh, o0); x[1] = ld_bf8(rh, o0 + 64u); x[2] = ld_bf8(rh, o1); x[3] = ld_bf8(rh, o1 + 64u);
+                q.x[0] = ld_bf8(rh, o0); q.x[1] = ld_bf8(rh, o0 + 64u); q.x[2] = ld_bf8(rh, o1); q.x[3] = ld_bf8(rh, o1 + 64u);
             }
+        };
+        for (int t0 = ts; t0 < te; t0 += 16) {
+            const int t = t0 + n;
+            const bool ok = t < te;
+            const unsigned pos = (unsigned)(b * a.Tp + t0);
+            Loads cur;
+            fetch(t0, cur);
+            f32x4 (&D)[NM] = cur.D;
+            bf16x8 (&du)[12] = cur.du;
+            bf16x8 (&x)[4] = cur.x;
+            const float au0 = cur.au0, au1 = cur.au1;
             // ---- d h_{l+1}: highway carry + data gradient of the layer above + the skip path's share
+            {
+                const unsigned char* ab = s_dg + (mb * 12 * 64 + lane) * 16;
 #pragma unroll
-            for (int ks = KS0; ks < KS1; ++ks)
+                for (int ks = KS0; ks < KS1; ++ks)
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(s_dg + ((m * 12 + ks) * 64 + lane) * 16);
-                    D[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, du[ks], D[m], 0, 0, 0);
-                }
+                    for (int m = 0; m < NM; ++m) {
+                        const bf16x8 af = *reinterpret_cast<const bf16x8*>(ab + ((m * 12 + ks) * 64) * 16);
+                        D[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, du[ks], D[m], 0, 0, 0);
+                    }
+            }
             if (MODE == 2) {                       // input layer: h_0 = softsign(pre), pre = cb + [t >= 1](cv0 x(t-1) + cc0) + cv1 x(t) + cc1
                 const float m0 = t >= 1 ? 1.f : 0.f;
 #pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    const int ch = chan_of(m, g, 0);
-                    const f32x4 kb = *reinterpret_cast<const f32x4*>(cst + ch), v0 = *reinterpret_cast<const f32x4*>(cst + 64 + ch),
-                                v1 = *reinterpret_cast<const f32x4*>(cst + 128 + ch), c0 = *reinterpret_cast<const f32x4*>(cst + 192 + ch),
-                                c1 = *reinterpret_cast<const f32x4*>(cst + 256 + ch);
+                for (int m = 0; m < NM; ++m) {
+                    const float* cp = cst + chb + 8 * g + 32 * (m >> 1) + 4 * (m & 1);
+                    const f32x4 kb = *reinterpret_cast<const f32x4*>(cp), v0 = *reinterpret_cast<const f32x4*>(cp + 64),
+                                v1 = *reinterpret_cast<const f32x4*>(cp + 128), c0 = *reinterpret_cast<const f32x4*>(cp + 192),
+                                c1 = *reinterpret_cast<const f32x4*>(cp + 256);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float pre = kb[r] + m0 * fmaf(v0[r], au0, c0[r]) + fmaf(v1[r], au1, c1[r]);
@@ -283,37 +310,48 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
                 }
                 continue;
             }
-            // ---- gate pre-activations
-            f32x4 acc[8];
+            // ---- gate pre-activations: rows of the wave's channels, gate (tiles mb + m) and candidate (4 + mb + m)
+            f32x4 acc[2 * NM];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                acc[m] = *reinterpret_cast<const f32x4*>(cst + chan_of(m, g, 0));
-                acc[4 + m] = *reinterpret_cast<const f32x4*>(cst + H + chan_of(m, g, 0));
+            for (int m = 0; m < NM; ++m) {
+                const float* cp = cst + chb + 8 * g + 32 * (m >> 1) + 4 * (m & 1);
+                acc[m] = *reinterpret_cast<const f32x4*>(cp);
+                acc[NM + m] = *reinterpret_cast<const f32x4*>(cp + H);
             }
+            {
+                const unsigned char* az = s_rec + (mb * 4 * 64 + lane) * 16;
+                const unsigned char* ac = s_rec + ((4 + mb) * 4 * 64 + lane) * 16;
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
+                for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
-                for (int mt = 0; mt < 8; ++mt) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(s_rec + ((mt * 4 + ks) * 64 + lane) * 16);
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, x[ks], acc[mt], 0, 0, 0);
-                }
+                    for (int m = 0; m < NM; ++m) {
+                        const bf16x8 fz = *reinterpret_cast<const bf16x8*>(az + ((m * 4 + ks) * 64) * 16);
+                        const bf16x8 fc = *reinterpret_cast<const bf16x8*>(ac + ((m * 4 + ks) * 64) * 16);
+                        acc[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fz, x[ks], acc[m], 0, 0, 0);
+                        acc[NM + m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fc, x[ks], acc[NM + m], 0, 0, 0);
+                    }
+            }
             // ---- gates and their derivatives (fp32)
             const float wu = wus[jj0 + (t0 - ts) + n];
             float pw = 0.f;
-            unsigned dav[2][8];
-            f32x4 eout[4];
+            unsigned dav[2][2 * NM];
+            f32x4 eout[NM];
+            // the wave's own channels of h(t): tap-1 fragment 2 + (tile >> 1)
+            const u32x4 hwa = __builtin_bit_cast(u32x4, x[2]), hwb = __builtin_bit_cast(u32x4, x[3]);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const float4 bz4 = *reinterpret_cast<const float4*>(cst + 128 + chan_of(m, g, 0));
-                const float4 bc4 = *reinterpret_cast<const float4*>(cst + 128 + H + chan_of(m, g, 0));
+            for (int m = 0; m < NM; ++m) {
+                const float* cp = cst + 128 + chb + 8 * g + 32 * (m >> 1) + 4 * (m & 1);
+                const float4 bz4 = *reinterpret_cast<const float4*>(cp);
+                const float4 bc4 = *reinterpret_cast<const float4*>(cp + H);
                 const float czv[4] = {cz[m].x, cz[m].y, cz[m].z, cz[m].w}, ccv[4] = {cc[m].x, cc[m].y, cc[m].z, cc[m].w};
                 const float bzv[4] = {bz4.x, bz4.y, bz4.z, bz4.w}, bcv[4] = {bc4.x, bc4.y, bc4.z, bc4.w};
-                const u32x4 hw = __builtin_bit_cast(u32x4, x[2 + (m >> 1)]);
+                u32x4 hw;
+                if (HALF) hw = mb ? hwb : hwa; else hw = (m >> 1) ? hwb : hwa;
                 float daz[4], dac[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float gz = fmaf(wu, czv[r], bzv[r]), gc = fmaf(wu, ccv[r], bcv[r]);
-                    const float az = acc[m][r], ac = acc[4 + m][r];
+                    const float az = acc[m][r], ac = acc[NM + m][r];
                     const float z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(K_SIG * gz * az));
                     const float q = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(K_TANH * gc * ac));
                     const float c = fmaf(-2.f, q, 1.f);
@@ -335,21 +373,22 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
             }
             // ---- stores: da (bf16, [t][128]) and E_l (fp32, [t][64])
             {
-                const unsigned so = ok ? pos * 256u + lane_d : OOB;
+                const unsigned so = ok ? pos * 256u + lane_d + chb * 2u : OOB;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int hlf = 0; hlf < 2; ++hlf) {
+                    for (int hlf = 0; hlf < NM / 2; ++hlf) {
                         const u32x4 v = {dav[q][4 * hlf], dav[q][4 * hlf + 1], dav[q][4 * hlf + 2], dav[q][4 * hlf + 3]};
                         __builtin_amdgcn_raw_buffer_store_b128(v, rdo, so + 128u * q + 64u * hlf, 0, 0);
                     }
-                const unsigned eo = ok ? pos * 256u + lane_e : OOB;
+                const unsigned eo = ok ? pos * 256u + lane_e + chb * 4u : OOB;
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < NM; ++m)
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, eout[m]), reo,
                                                            eo + (unsigned)(32 * (m >> 1) + 4 * (m & 1)) * 4u, 0, 0);
             }
-            // g w_up[jj] += sum_o2 dgx[o2][t] * cond[f][o2]: finish the sum over the four lane groups
+            // g w_up[jj] += sum_o2 dgx[o2][t] * cond[f][o2]: finish the sum over the four lane groups (and, through the LDS
+            // accumulator, over the two waves of a frame)
             pw += __shfl_xor(pw, 16);
             pw += __shfl_xor(pw, 32);
             if (g == 0 && ok) atomicAdd(gwl + jj0 + (t0 - ts) + n, pw);
@@ -359,31 +398,48 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
 #pragma unroll
             for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int m = 0; m < 4; ++m)
+                for (int m = 0; m < NM; ++m)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) dca[q][m][r] = row_sum16(dca[q][m][r]);
             if (n == 0) {
-                float* dst = a.dcond + ((size_t)b * a.Tf + f) * a.N + (size_t)l * 128;
+                float* dst = a.dcond + ((size_t)b * a.Tf + f) * a.N + (size_t)l * 128 + chb + 8 * g;
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
 #pragma unroll
-                    for (int m = 0; m < 4; ++m)
-                        *reinterpret_cast<float4*>(dst + q * H + chan_of(m, g, 0)) =
+                    for (int m = 0; m < NM; ++m)
+                        *reinterpret_cast<float4*>(dst + q * H + 32 * (m >> 1) + 4 * (m & 1)) =
                             make_float4(dca[q][m][0], dca[q][m][1], dca[q][m][2], dca[q][m][3]);
             }
         }
+        if (HALF) {                                // the wave's next unit may be the other half: flush its channel sums now
+#pragma unroll
+            for (int q = 0; q < (MODE == 2 ? 4 : 2); ++q)
+#pragma unroll
+                for (int m = 0; m < NM; ++m)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float& src = MODE == 2 ? inl[q][m][r] : gbx[q & 1][m][r];
+                        const float v = row_sum16(src);
+                        src = 0.f;
+                        float* dstl = MODE == 2 ? gwl : gbl;               // MODE 2: gwl | gbl are 256 contiguous floats
+                        if (n == 0) atomicAdd(dstl + q * H + chb + 8 * g + 4 * m + r, v);
+                    }
+        }
     }
-    if (MODE == 2) {                               // g cb = g cc tap 1 | g cv tap 0 | g cv tap 1 | g cc tap 0
+    if (!HALF) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int q = 0; q < (MODE == 2 ? 4 : 2); ++q)
 #pragma unroll
-            for (int m = 0; m < 4; ++m)
+            for (int m = 0; m < NM; ++m)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float v = row_sum16(inl[q][m][r]);
-                    if (n == 0) atomicAdd(gwl + q * H + chan_of(m, g, r), v);      // gwl | gbl: 256 contiguous floats
+                    const float v = row_sum16(MODE == 2 ? inl[q][m][r] : gbx[q & 1][m][r]);
+                    float* dstl = MODE == 2 ? gwl : gbl;
+                    if (n == 0) atomicAdd(dstl + q * H + chan_of(m, g, r), v);
                 }
-        __syncthreads();
+    }
+    __syncthreads();
+    if (MODE == 2) {                               // g cb = g cc tap 1 | g cv tap 0 | g cv tap 1 | g cc tap 0
         if (tid < 256) {
             const float v = gwl[tid];
             const int o = tid & 63;
@@ -393,16 +449,6 @@ __global__ __launch_bounds__(BW_THREADS, 1) void bl6_layer_bwd_kernel(const BwAr
         }
         return;
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-        for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float v = row_sum16(gbx[q][m][r]);
-                if (n == 0) atomicAdd(gbl + q * H + chan_of(m, g, r), v);
-            }
-    __syncthreads();
     if (tid < 128) atomicAdd(a.gP + a.y.bx + (size_t)l * 128 + tid, gbl[tid]);
     else if (tid - 128 < a.U) atomicAdd(a.gP + a.y.wup + tid - 128, gwl[tid - 128]);
 }
@@ -714,17 +760,27 @@ __global__ __launch_bounds__(HB_THREADS, 1) void bl6_head_bwd_kernel(const HbArg
     }
 }
 
-template <int MODE>
-int launch_layer(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, int grid, hipStream_t st) {
-    auto kern = bl6_layer_bwd_kernel<MODE>;
+template <int MODE, bool HALF>
+int launch_layer_h(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, hipStream_t st) {
+    auto kern = bl6_layer_bwd_kernel<MODE, HALF>;
     static bool attr_done = false;                                // per instantiation; the attribute is per function
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS) != hipSuccess)
             return SWN_E_LAUNCH;
         attr_done = true;
     }
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(BW_THREADS), BW_LDS, st, a, l, dil, dil_up, n_units, Fu);
+    constexpr int wpw = BwShape<HALF>::THREADS / 64;
+    const int jobs = HALF ? 2 * n_units : n_units;
+    const int grid = (jobs + wpw - 1) / wpw < 256 ? (jobs + wpw - 1) / wpw : 256;     // one workgroup per CU
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(BwShape<HALF>::THREADS), BW_LDS, st, a, l, dil, dil_up, n_units, Fu);
     return SWN_OK;
+}
+// half-frame units while the frames alone cannot fill the chip's wave slots twice over (see BwShape)
+template <int MODE>
+int launch_layer(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, hipStream_t st) {
+    // (the last launch carries 64 more accumulators per lane for the input layer: always in halves, or it spills)
+    return (MODE == 2 || n_units < 2 * 2048) ? launch_layer_h<MODE, true>(a, l, dil, dil_up, n_units, Fu, st)
+                                             : launch_layer_h<MODE, false>(a, l, dil, dil_up, n_units, Fu, st);
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -801,14 +857,12 @@ int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed,
     // ---- gated layers, input layer
     const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;               // frame units per utterance
     const int n_units = B * Fu;
-    const int wpw = BW_THREADS / 64;
-    const int grid = (n_units + wpw - 1) / wpw < 256 ? (n_units + wpw - 1) / wpw : 256;   // one workgroup per CU
     int rc = SWN_OK;
     for (int l = g.L - 1; l >= 0 && rc == SWN_OK; --l) {
-        if (l == g.L - 1) rc = launch_layer<0>(a, l, g.dil[l], 1, n_units, Fu, grid, st);
-        else rc = launch_layer<1>(a, l, g.dil[l], g.dil[l + 1], n_units, Fu, grid, st);
+        if (l == g.L - 1) rc = launch_layer<0>(a, l, g.dil[l], 1, n_units, Fu, st);
+        else rc = launch_layer<1>(a, l, g.dil[l], g.dil[l + 1], n_units, Fu, st);
     }
-    if (rc == SWN_OK) rc = launch_layer<2>(a, -1, 1, g.dil[0], n_units, Fu, grid, st);
+    if (rc == SWN_OK) rc = launch_layer<2>(a, -1, 1, g.dil[0], n_units, Fu, st);
     if (rc != SWN_OK) return rc;
     // ---- weight gradients: L dil_h jobs, L/2 out_skip column blocks, out_1
     {
