@@ -136,7 +136,7 @@ class StackFunction(torch.autograd.Function):
         raw, saved = net.forward_train(aux, audio, drop=getattr(module, "_pending_drop", None))
         module._pending_drop = None
         ctx.net, ctx.saved, ctx.module = net, saved, module
-        ctx.plist = [p.detach() for p in params]       # Module.parameters() order = state_dict order
+        ctx.plist = params                             # Module.parameters() order = state_dict order (leaves: no cycle)
         return raw
 
     @staticmethod
@@ -147,7 +147,7 @@ class StackFunction(torch.autograd.Function):
         out = unfold_packed_grads_device(ctx.net, gp, ctx.plist, want) if (fp32 and ctx.module.device_unfold) else None
         if out is None:                                # torch-op version (aux_conv2d_flag, or switched off for A/B tests)
             names = [k for k, _ in ctx.module.named_parameters()]
-            pd = dict(zip(names, ctx.plist))
+            pd = dict(zip(names, [p.detach() for p in ctx.plist]))
             grads = unfold_packed_grads(ctx.net.cfg, gp, pd)
             out = [grads[k].reshape(pd[k].shape).contiguous() if want[i] else None for i, k in enumerate(names)]
         return (None, None, None, *out)

@@ -139,8 +139,18 @@ class HipNet:
 
     def repack(self, tensors: Sequence[torch.Tensor]) -> None:
         """refresh the packed buffer IN PLACE from the live parameter tensors on the device (after an optimizer
-        step); launches are stream-ordered behind whatever still reads the old values."""
-        pack_parameters_device(self.cfg, tensors, out=self.packed)
+        step); launches are stream-ordered behind whatever still reads the old values.  The per-tensor validation of
+        pack_parameters_device is done once per set of storages: an optimizer step changes values, not addresses."""
+        key = tuple(t.data_ptr() for t in tensors)
+        cached = getattr(self, "_repack_cache", None)
+        if cached is None or cached[0] != key or any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+            pack_parameters_device(self.cfg, tensors, out=self.packed)       # validates shapes / devices / dtypes
+            if all(t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+                self._repack_cache = (key, (ctypes.c_void_p * len(key))(*key))
+        else:
+            with _ops._on(self.device):
+                _lib.check(self.lib.swn_pack_params_device(ctypes.byref(self.desc), cached[1], len(key), _ptr(self.packed),
+                                                           self.packed.numel(), _stream_ptr(self.device)), "pack_params_device")
         self.packed_version += 1
 
     @classmethod
