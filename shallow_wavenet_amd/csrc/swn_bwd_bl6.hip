@@ -228,8 +228,10 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
                 for (int r = 0; r < 4; ++r) dca[q][m][r] = 0.f;
 
         // every load of a chunk is issued together.  (Issuing the NEXT chunk's loads ahead of the current chunk's work - eight
-        // waves, the freed registers holding them - was slower, 84 us per layer: what separates a frame's dependent chunks is
-        // not memory latency but the chunk's own chain of LDS-fed MFMAs and transcendentals, which more waves hide better.)
+        // waves, the freed registers holding them, pinned by a scheduling barrier - was slower, 84-86 us per layer: what
+        // separates a frame's dependent chunks is not memory latency but the chunk's own chain: the compiler's schedule of the
+        // LDS-fed MFMAs is read, read, wait, MFMA - one LDS latency per MFMA - and a sched_group_barrier pipeline made it
+        // read, wait(0), MFMA.  More waves hide it better than anything tried inside one wave.)
         struct Loads { f32x4 D[NM]; bf16x8 du[12]; bf16x8 x[4]; float au0, au1; };
         auto fetch = [&](const int t0, Loads& q) {
             const int t = t0 + n;
@@ -274,6 +276,10 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
             const unsigned pos = (unsigned)(b * a.Tp + t0);
             Loads cur;
             fetch(t0, cur);
+            // keep the loads HERE: left alone, the scheduler sinks each one next to its use to save registers, and the chunk
+            // pays a memory round trip per k-step instead of one (whole-frame form at 64 x 16 500: 364 -> 329-347 us per layer,
+            // 4.7-4.96 TB/s).  Not in the twelve-wave form: at 170 registers the pinned loads spill (68 -> 72 us).
+            if (!HALF || MODE == 2) __builtin_amdgcn_sched_barrier(0);
             f32x4 (&D)[NM] = cur.D;
             bf16x8 (&du)[12] = cur.du;
             bf16x8 (&x)[4] = cur.x;
