@@ -680,15 +680,18 @@ __global__ __launch_bounds__(HB_THREADS, 1) void bl6_head_bwd_kernel(const HbArg
         }
         __syncthreads();                                                   // (A) bt published
         // ---- skip = Wsk . [h_1 .. h_L]
+        // k-step outer, the four column tiles' fragments read as one batch: four LDS reads in flight per four MFMAs (column
+        // tile outer, the schedule was read, read, wait, MFMA: one LDS latency per MFMA)
         f32x4 s1v[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            s1v[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 4; ++nt) s1v[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 12; ++ks) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(bt + ((nt * 12 + ks) * 64 + lane) * 16);
-                s1v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[ks], bf, s1v[nt], 0, 0, 0);
-            }
+        for (int ks = 0; ks < 12; ++ks) {
+            bf16x8 bf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(bt + ((nt * 12 + ks) * 64 + lane) * 16);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) s1v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(Ask[ks], bf[nt], s1v[nt], 0, 0, 0);
         }
         auto put = [&](unsigned char* tl, const int nt, const f32x4& v) {   // rows 16w + 4g .. + 3 of position 16nt + n
             uint2 pk; pk.x = pack2(v[0], v[1]); pk.y = pack2(v[2], v[3]);
@@ -704,13 +707,17 @@ __global__ __launch_bounds__(HB_THREADS, 1) void bl6_head_bwd_kernel(const HbArg
         // ---- out_1 and d out_1
         f32x4 r1v[4], dv[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            r1v[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int nt = 0; nt < 4; ++nt) r1v[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(t1 + (16 * nt + n) * HB_ROW + (32 * ks + 8 * g) * 2);
-                r1v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[ks], bf, r1v[nt], 0, 0, 0);
-            }
+        for (int ks = 0; ks < 4; ++ks) {
+            bf16x8 bf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(t1 + (16 * nt + n) * HB_ROW + (32 * ks + 8 * g) * 2);
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) r1v[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1[ks], bf[nt], r1v[nt], 0, 0, 0);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
             dv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A2T, dyb[nt], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -732,17 +739,24 @@ __global__ __launch_bounds__(HB_THREADS, 1) void bl6_head_bwd_kernel(const HbArg
             if (w == 0) acc_b2 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dya[k2], __builtin_bit_cast(bf16x8, ones), acc_b2, 0, 0, 0);
         }
         // ---- d skip = [s1 > 0] . W1^T d out_1
+        {
+            f32x4 kv[4];
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            f32x4 kv = {0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 4; ++nt) kv[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(t3 + (16 * nt + n) * HB_ROW + (32 * ks + 8 * g) * 2);
-                kv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1T[ks], bf, kv, 0, 0, 0);
+                bf16x8 bf[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) bf[nt] = *reinterpret_cast<const bf16x8*>(t3 + (16 * nt + n) * HB_ROW + (32 * ks + 8 * g) * 2);
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) kv[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(A1T[ks], bf[nt], kv[nt], 0, 0, 0);
             }
 #pragma unroll
-            for (int r = 0; r < 4; ++r) kv[r] = s1v[nt][r] > 0.f ? kv[r] : 0.f;
-            put(t4, nt, kv);
+            for (int nt = 0; nt < 4; ++nt) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) kv[nt][r] = s1v[nt][r] > 0.f ? kv[nt][r] : 0.f;
+                put(t4, nt, kv[nt]);
+            }
         }
         __syncthreads();                                                   // (D) t4 complete
         // ---- s1, d out_1, d skip -> HBM, whole 256-byte rows
