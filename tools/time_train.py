@@ -14,6 +14,7 @@ train_precision(MODE)
 ONLY = sys.argv[4].upper() if len(sys.argv) > 4 else None      # optional 4th argument: bl6 | ref6
 WITH_OPT = len(sys.argv) > 5 and sys.argv[5] == "opt"           # optional 5th argument "opt": Adam step inside the loop
 CHAIN = len(sys.argv) > 6 and sys.argv[6] == "chain"            # optional 6th argument "chain": generic per-layer backward
+FUSED_ADAM = "fused_adam" in sys.argv                            # anywhere: torch.optim.Adam(fused=True)
 for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     if ONLY and nm != ONLY:
         continue
@@ -28,7 +29,7 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
 
     for p in m.scale_in.parameters():
         p.requires_grad = False
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4, **({"fused": True} if FUSED_ADAM else {}))
 
     def step():
         if CHAIN:
