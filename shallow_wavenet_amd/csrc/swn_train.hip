@@ -733,69 +733,82 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
 //      threads 64..255  thread = upsampler tap jj:  gwup[jj] += sum_{s,o2} dgx[o2][t] * cond[b][f][(l*seg+s)*2H+o2]
 //      with t = f*U + jj - s - coff  (the positions whose conditioning comes from frame f, tap jj)
 __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* __restrict__ dcond, float* __restrict__ gbx,
-                                                       float* __restrict__ gwup) {
-    // workgroup = (64 in_x rows, frame f, utterance b).  The U + seg - 1 positions the frame touches are staged
-    // through LDS with coalesced loads (lanes along t; it used to be one strided stream per thread, thrashing L1),
+                                                       float* __restrict__ gwup, const int FR) {
+    // workgroup = (64 in_x rows, FR consecutive frames, utterance b).  Per frame the U + seg - 1 positions it touches are
+    // staged through LDS with coalesced loads (lanes along t; it used to be one strided stream per thread, thrashing L1),
     // then one thread per row does its U x seg multiply-adds out of LDS (row pitch odd: conflict-free).
-    // pitch = the frame's U + seg - 1 columns rounded up to odd (a fixed 273-float pitch for U <= 256 held the kernel at
-    // two workgroups per CU: 182 us per layer at REF6, latency-bound)
+    // The sums over frames (g b_inx per row, g w_up per tap) stay in registers across the FR frames and leave as ONE
+    // atomic each: with one frame per workgroup every w_up tap took B x Tf x 2H/64 = 7 200 same-address atomics per layer
+    // at REF6, which - not the 200 MB of dgx - was what the 182 us of this kernel were.
     extern __shared__ float tile_mem[];
     const int pitch = (a.g.U + a.g.seg - 1) | 1;
     auto tile = [&](int r, int c) -> float& { return tile_mem[r * pitch + c]; };
     __shared__ float wus[256];
     __shared__ float cs[10][64];                 // seg <= 10 (swn_make_geom)
     const SwnGeom& g = a.g;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, f = blockIdx.y, b = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.z;
     const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
-    const int tbeg = f * U - (seg - 1) - a.coff, ncol = U + seg - 1;           // tile column c <-> position tbeg + c
+    const int ncol = U + seg - 1;
     wus[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
-    for (int e = tid; e < seg * 64; e += 256) {                                 // this frame's in_x products for the 64 rows
-        const int sx = e >> 6, o2 = blockIdx.x * 64 + (e & 63);
-        cs[sx][e & 63] = o2 < H2 ? a.cond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + sx) * H2 + o2] : 0.f;
-    }
-    {   // 16 rows per wave, all 16 loads of a 64-column chunk in flight (branch-free: out-of-range offset = zero)
-        const __amdgpu_buffer_rsrc_t rD = rsrc_of(a.dgx + (size_t)b * H2 * a.Tp);
+    const __amdgpu_buffer_rsrc_t rD = rsrc_of(a.dgx + (size_t)b * H2 * a.Tp);
+    const int o2 = blockIdx.x * 64 + tid;
+    float bsum = 0.f, wacc[2] = {0.f, 0.f};      // tid < 64: row sum ; tid >= 64: taps tid - 64 and tid + 128
+    const int f1 = (blockIdx.y + 1) * FR < a.Tf ? (blockIdx.y + 1) * FR : a.Tf;
+    for (int f = blockIdx.y * FR; f < f1; ++f) {
+        const int tbeg = f * U - (seg - 1) - a.coff;                              // tile column c <-> position tbeg + c
+        for (int e = tid; e < seg * 64; e += 256) {                               // this frame's in_x products for the 64 rows
+            const int sx = e >> 6, r2 = blockIdx.x * 64 + (e & 63);
+            cs[sx][e & 63] = r2 < H2 ? a.cond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + sx) * H2 + r2] : 0.f;
+        }
+        // 16 rows per wave, all 16 loads of a 64-column chunk in flight (branch-free: out-of-range offset = zero)
         for (int c = lane; c < ncol; c += 64) {
             const int t = tbeg + c;
             const bool tok = t >= 0 && t < a.Tp;
             float v[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int o2 = blockIdx.x * 64 + w + 4 * i;
-                v[i] = bld1(rD, (tok && o2 < H2) ? (unsigned)(((size_t)o2 * a.Tp + t) * 4) : SWN_OOB);
+                const int r2 = blockIdx.x * 64 + w + 4 * i;
+                v[i] = bld1(rD, (tok && r2 < H2) ? (unsigned)(((size_t)r2 * a.Tp + t) * 4) : SWN_OOB);
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) tile(w + 4 * i, c) = v[i];
         }
-    }
-    __syncthreads();
-    if (tid >= 64) {
-        // the other orientation of the same tile (was a second pass over dgx, wup_bwd_kernel): thread = upsampler tap jj,
-        // gwup[jj] += sum_{s, rows} dgx[row][t(jj, s)] * cond[f][(l*seg+s)*2H + row]   (columns: conflict-free, pitch odd)
-        for (int jj = tid - 64; jj < U; jj += 192) {
-            float acc = 0.f;
-            for (int sx = 0; sx < seg; ++sx) {
-                const int c = jj + (seg - 1) - sx;
+        __syncthreads();
+        if (tid >= 64) {
+            // the other orientation of the same tile (was a second pass over dgx, wup_bwd_kernel): thread = upsampler tap jj,
+            // gwup[jj] += sum_{s, rows} dgx[row][t(jj, s)] * cond[f][(l*seg+s)*2H + row]   (columns: conflict-free, pitch odd)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int jj = tid - 64 + 192 * q;
+                if (jj < U) {
+                    float acc = 0.f;
+                    for (int sx = 0; sx < seg; ++sx) {
+                        const int c = jj + (seg - 1) - sx;
 #pragma unroll 8
-                for (int r = 0; r < 64; ++r) acc = fmaf(tile(r, c), cs[sx][r], acc);
+                        for (int r = 0; r < 64; ++r) acc = fmaf(tile(r, c), cs[sx][r], acc);
+                    }
+                    wacc[q] += acc;
+                }
             }
-            atomicAdd(gwup + jj, acc);
+        } else if (o2 < H2) {
+            for (int s = 0; s < seg; ++s) {
+                float dsum = 0.f;
+                for (int jj = 0; jj < U; ++jj) {
+                    const float d = tile(tid, jj + (seg - 1) - s);       // t = f*U + jj - s - coff
+                    dsum = fmaf(wus[jj], d, dsum);
+                    if (s == 0) bsum += d;                               // every position belongs to exactly one (f, jj) at s = 0
+                }
+                dcond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + s) * H2 + o2] = dsum;
+            }
         }
-        return;
+        __syncthreads();                                                   // the tile is free for the next frame
     }
-    const int o2 = blockIdx.x * 64 + tid;
-    if (o2 >= H2) return;
-    float bsum = 0.f;
-    for (int s = 0; s < seg; ++s) {
-        float dsum = 0.f;
-        for (int jj = 0; jj < U; ++jj) {
-            const float d = tile(tid, jj + (seg - 1) - s);           // t = f*U + jj - s - coff
-            dsum = fmaf(wus[jj], d, dsum);
-            if (s == 0) bsum += d;                                   // every position belongs to exactly one (f, jj) at s = 0
-        }
-        dcond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + s) * H2 + o2] = dsum;
+    if (tid >= 64) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int jj = tid - 64 + 192 * q; if (jj < U) atomicAdd(gwup + jj, wacc[q]); }
+    } else if (o2 < H2) {
+        atomicAdd(gbx + (size_t)l * H2 + o2, bsum);
     }
-    atomicAdd(gbx + (size_t)l * H2 + o2, bsum);
 }
 
 
@@ -1189,9 +1202,12 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             launch_time(t, B, st);
         }
         if (!drop) {
-            hipLaunchKernelGGL(cond_bwd_kernel, dim3((H2 + 63) / 64, n_frames, B), dim3(256),
+            // frames per workgroup: as many as still leave ~768 workgroups
+            const int rb = (H2 + 63) / 64;
+            int FR = (int)(((long)rb * n_frames * B) / 768); FR = FR < 1 ? 1 : (FR > 16 ? 16 : FR);
+            hipLaunchKernelGGL(cond_bwd_kernel, dim3(rb, (n_frames + FR - 1) / FR, B), dim3(256),
                                (size_t)64 * ((g.U + g.seg - 1) | 1) * sizeof(float), st, ga, dcond, gpacked + y.bx,
-                               gpacked + y.wup);
+                               gpacked + y.wup, FR);
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
             {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
