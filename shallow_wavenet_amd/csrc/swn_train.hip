@@ -1000,26 +1000,65 @@ namespace {
 
 // dropout mode, conditioning side: dx = dxm * drop_x ; dC[b][c][f] = sum_j dx[c][f*U+j-coff] w_up[j] ;
 // g w_up[j] += sum dx * C ; g b_up += sum dx          (backward of xm_fwd_kernel, csrc/swn_stack.hip)
+// Workgroup = (FR frames, 32 channels, utterance); a wave takes channels w, w+4, ..., its lanes the taps j = lane + 64 q.
+// The sums over channels and frames (g w_up per tap, g b_up) stay in registers and leave as one atomic per tap and
+// workgroup.  (One workgroup per (frame, channel, utterance) with one atomic per thread: 32 M atomics onto 110 addresses
+// at the run.sh geometry - 14 ms of a 47 ms step.)
+constexpr int XM_CC = 32;
 __global__ __launch_bounds__(256) void xm_bwd_kernel(const float* __restrict__ dxm, const float* __restrict__ drop_x,
                                                      const float* __restrict__ C, const float* __restrict__ P, size_t wup,
                                                      float* __restrict__ dC, float* __restrict__ gwup, float* __restrict__ gbup,
-                                                     int A0, int Tf, int U, int coff, int Tx) {
-    __shared__ float red[256];
-    const int j = threadIdx.x, f = blockIdx.x, c = blockIdx.y, b = blockIdx.z;
-    const int u = f * U + j - coff;
-    float dx = 0.f;
-    if (j < U && u >= 0 && u < Tx) { const size_t o = ((size_t)b * A0 + c) * Tx + u; dx = dxm[o] * drop_x[o]; }
-    const float cv = C[((size_t)b * A0 + c) * Tf + f];
-    if (j < U && dx != 0.f) atomicAdd(gwup + j, dx * cv);
-    red[j] = j < U ? dx * P[wup + j] : 0.f;
+                                                     int A0, int Tf, int U, int coff, int Tx, int FR) {
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.z;
+    const int c0 = blockIdx.y * XM_CC;
+    float wu[4], gw[4] = {0.f, 0.f, 0.f, 0.f}, gb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wu[q] = lane + 64 * q < U ? P[wup + lane + 64 * q] : 0.f;
+    const __amdgpu_buffer_rsrc_t rX = rsrc_of(dxm + (size_t)b * A0 * Tx), rM = rsrc_of(drop_x + (size_t)b * A0 * Tx);
+    const int f1 = (blockIdx.x + 1) * FR < Tf ? (blockIdx.x + 1) * FR : Tf;
+    for (int f = blockIdx.x * FR; f < f1; ++f) {
+        unsigned off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q, u = f * U + j - coff;
+            off[q] = (j < U && u >= 0 && u < Tx) ? (unsigned)(u * 4) : SWN_OOB;
+        }
+        for (int ci = w; ci < XM_CC; ci += 8) {                  // two channels per pass: 16 loads in flight
+            float x[2][4], m[2][4], cv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + ci + 4 * h;
+                const unsigned ro = c < A0 ? (unsigned)((size_t)c * Tx * 4) : SWN_OOB;
+                cv[h] = c < A0 ? C[((size_t)b * A0 + c) * Tf + f] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const unsigned o = ((off[q] | ro) & SWN_OOB) ? SWN_OOB : off[q] + ro;
+                    x[h][q] = bld1(rX, o); m[h][q] = bld1(rM, o);
+                }
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + ci + 4 * h;
+                float part = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dx = x[h][q] * m[h][q];
+                    gw[q] = fmaf(dx, cv[h], gw[q]); part = fmaf(dx, wu[q], part); gb += dx;
+                }
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
+                if (lane == 0 && c < A0) dC[((size_t)b * A0 + c) * Tf + f] = part;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[w][lane + 64 * q] = gw[q];
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) gb += __shfl_xor(gb, sft);
     __syncthreads();
-    for (int sft = 128; sft > 0; sft >>= 1) { if (j < sft) red[j] += red[j + sft]; __syncthreads(); }
-    if (j == 0) dC[((size_t)b * A0 + c) * Tf + f] = red[0];
-    __syncthreads();
-    red[j] = dx;
-    __syncthreads();
-    for (int sft = 128; sft > 0; sft >>= 1) { if (j < sft) red[j] += red[j + sft]; __syncthreads(); }
-    if (j == 0 && red[0] != 0.f) atomicAdd(gbup, red[0]);
+    if (tid < U) atomicAdd(gwup + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+    if (lane == 0 && gb != 0.f) atomicAdd(gbup, gb);
 }
 
 }  // namespace
@@ -1240,8 +1279,10 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         for (int i = 0; i < g.auxl; ++i) { chn[i + 1] = g.aux_cout[i]; act[i + 1] = p; dact[i + 1] = q; p += bt * g.aux_cout[i]; q += bt * g.aux_cout[i]; }
         const float* C = act[g.auxl];
         if (drop) {
-            hipLaunchKernelGGL(xm_bwd_kernel, dim3(n_frames, g.A0, B), dim3(256), 0, st, dxm, drop_x, C, packed, y.wup,
-                               dact[g.auxl], gpacked + y.wup, gpacked + y.bup, g.A0, n_frames, g.U, coff, Tx);
+            const int cb = (g.A0 + XM_CC - 1) / XM_CC;
+            int FRx = (int)(((long)cb * n_frames * B) / 1024); FRx = FRx < 1 ? 1 : (FRx > 16 ? 16 : FRx);
+            hipLaunchKernelGGL(xm_bwd_kernel, dim3((n_frames + FRx - 1) / FRx, cb, B), dim3(256), 0, st, dxm, drop_x, C, packed, y.wup,
+                               dact[g.auxl], gpacked + y.wup, gpacked + y.bup, g.A0, n_frames, g.U, coff, Tx, FRx);
         } else
         {   // dC[b][c][f] = sum_n Wx[n][c] dcond[b][f][n] ; gWx[n][c] += sum_{b,f} dcond[b][f][n] C[b][c][f]
             TimeGemm t = {packed + y.wx, 1, 0, g.A0p, dcond, (long)n_frames * g.N, 1, g.N, dact[g.auxl], (long)g.A0 * n_frames, n_frames,

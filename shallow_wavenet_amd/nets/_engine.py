@@ -128,6 +128,16 @@ class EngineMixin:
 NOISE_SOURCES = ("host", "device")
 
 
+def dropout_device(module):
+    """where the nn.Dropout masks of a training-mode forward are drawn: `module.dropout_source` = "device" (default: the
+    module's own device, like nn.Dropout of the reference on a GPU) | "host" (torch CPU generator in the reference's draw
+    order: reproduces a CPU run of the reference mask for mask under torch.manual_seed - the g5_drop_* fixtures)."""
+    src = getattr(module, "dropout_source", None) or "device"
+    if src not in NOISE_SOURCES:
+        raise ValueError(f"dropout_source must be one of {NOISE_SOURCES} or None, not {src!r}")
+    return None if src == "host" else module._param_list()[0].device
+
+
 def resolve_noise_source(module, default: str) -> str:
     """`module.noise_source`: "host" | "device" | None (= the model's default)."""
     src = getattr(module, "noise_source", None) or default

@@ -33,7 +33,8 @@ if _PKG_PARENT not in sys.path:            # importable as top-level `cswnv_shif
 from shallow_wavenet_amd.config import NetConfig                      # noqa: E402
 from shallow_wavenet_amd import noise as _noise                       # noqa: E402
 from shallow_wavenet_amd.nets._engine import (                        # noqa: E402,F401
-    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, initialize, log_decode_speed, resolve_noise_source)
+    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, dropout_device, initialize, log_decode_speed,
+    resolve_noise_source)
 
 
 class CSWNV(EngineMixin, nn.Module):
@@ -113,7 +114,8 @@ class CSWNV(EngineMixin, nn.Module):
         # still follows `do`
         two = self.dilation_depth * self.dilation_repeat <= 2
         if self.do_prob > 0 and self.training and (do or two):
-            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob, draw_x=bool(do))
+            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob, draw_x=bool(do),
+                                        device=dropout_device(self))
         if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list())):
             # training: HIP forward + HIP backward behind autograd Functions (nets/_autograd.py)
             from shallow_wavenet_amd.nets._autograd import LaplaceHeadFunction, StackFunction

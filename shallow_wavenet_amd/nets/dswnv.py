@@ -27,7 +27,8 @@ if _PKG_PARENT not in sys.path:
 from shallow_wavenet_amd.config import NetConfig                      # noqa: E402
 from shallow_wavenet_amd import noise as _noise                       # noqa: E402
 from shallow_wavenet_amd.nets._engine import (                        # noqa: E402,F401
-    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, initialize, log_decode_speed, resolve_noise_source)
+    CausalConv1d, EngineMixin, TwoSidedDilConv1d, UpSampling, dropout_device, initialize, log_decode_speed,
+    resolve_noise_source)
 
 
 def encode_mu_law(x, mu=256):
@@ -130,7 +131,7 @@ class DSWNV(EngineMixin, nn.Module):
         idx = self._indices(audio, self.n_quantize)
         drop = None
         if do and self.do_prob > 0 and self.training:          # nn.Dropout acts in training mode only
-            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob)
+            drop = _noise.dropout_masks(self._cfg, aux.shape[0], aux.shape[2], self.do_prob, device=dropout_device(self))
         if drop is not None or (torch.is_grad_enabled() and any(p.requires_grad for p in self._param_list())):
             from shallow_wavenet_amd.nets._autograd import StackFunction
             self._pending_drop = drop

@@ -126,6 +126,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--verbose", default=1, type=int)
     p.add_argument("--synthetic", default=0, type=int)
     p.add_argument("--max_iters", default=0, type=int)
+    p.add_argument("--dropout_source", default="device", choices=["device", "host"],
+                   help="where the nn.Dropout masks are drawn: the model's device (like the reference on a GPU) or the torch "
+                        "CPU generator in the reference's order (reproduces a CPU run of the reference; ~1 s per chunk)")
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                    help="arithmetic of the training step's contractions (not a reference flag): fp32 = parity mode, "
                         "bf16 = bf16 operands with fp32 accumulation (swn_train_set_precision)")
@@ -158,6 +161,7 @@ def main(argv=None) -> int:
                   aux_kernel_size=args.aux_kernel_size, aux_dilation_size=args.aux_dilation_size,
                   audio_in_flag=args.audio_in, do_prob=args.do_prob, wav_conv_flag=args.wav_conv_flag,
                   upsampling_factor=args.upsampling_factor)
+    model.dropout_source = args.dropout_source
     logging.info(model)
     criterion = torch.nn.CrossEntropyLoss().cuda()
     dev = torch.device("cuda")

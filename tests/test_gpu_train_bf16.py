@@ -156,6 +156,7 @@ def test_dropout_gradients_bf16_mode(gpu_ok, name):
     of the reference's, gradients within the tensor-norm tolerance of the reference's own gradients."""
     cfg, d = load_golden(name)
     m = mc.CSWNV(**cfg.ctor_kwargs(), do_prob=float(d["drop_p"]))
+    m.dropout_source = "host"            # fixture = the reference's CPU masks
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=int(d["wseed"]), flavor=str(d["flavor"])).items()})
     m.cuda().train()
     tgt = torch.from_numpy(d["loss_target"]).cuda()

@@ -21,6 +21,7 @@ pytestmark = pytest.mark.gpu
 def test_training_chunk_matches_reference_modules(gpu_ok, name):
     cfg, d = load_golden(name)
     m = mc.CSWNV(**cfg.ctor_kwargs(), do_prob=float(d["drop_p"]))
+    m.dropout_source = "host"            # fixture = the reference's CPU masks
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=int(d["wseed"]), flavor="trained").items()})
     m.cuda().train()
     for p in m.scale_in.parameters():
@@ -59,6 +60,7 @@ def test_softmax_training_chunk_matches_reference_module(gpu_ok):
     name = "g6_trainstep_tiny_softmax"
     cfg, d = load_golden(name)
     m = md.DSWNV(**cfg.ctor_kwargs(), do_prob=float(d["drop_p"]))
+    m.dropout_source = "host"            # fixture = the reference's CPU masks
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=int(d["wseed"]), flavor="xavier").items()})
     m.cuda().train()
     for p in m.scale_in.parameters():

@@ -15,10 +15,11 @@ ONLY = sys.argv[4].upper() if len(sys.argv) > 4 else None      # optional 4th ar
 WITH_OPT = len(sys.argv) > 5 and sys.argv[5] == "opt"           # optional 5th argument "opt": Adam step inside the loop
 CHAIN = len(sys.argv) > 6 and sys.argv[6] == "chain"            # optional 6th argument "chain": generic per-layer backward
 FUSED_ADAM = "fused_adam" in sys.argv                            # anywhere: torch.optim.Adam(fused=True)
+DROP = 0.5 if "drop" in sys.argv else 0.0                        # anywhere "drop": do_prob = 0.5 and forward(do=True), as run.sh trains
 for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     if ONLY and nm != ONLY:
         continue
-    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m = mc.CSWNV(**dict(cfg.ctor_kwargs(), do_prob=DROP))
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True).items()})
     m.cuda().train()
     aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
@@ -34,7 +35,7 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     def step():
         if CHAIN:
             m._engine().fused_backward = False
-        res = m(aux, audio)
+        res = m(aux, audio, do=DROP > 0)
         mu, b, log_b = res[0].reshape(B, Tp), res[1].reshape(B, Tp), res[2].reshape(B, Tp)
         loss = mc.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
         for p in m.parameters():
@@ -56,4 +57,4 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     macs_fwd = (cfg.L * (2 * cfg.H * cfg.H * cfg.K + cfg.S * cfg.H) + cfg.S * cfg.S + cfg.n_out * cfg.S) * B * Tp
-    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}{' chain' if CHAIN else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops); host issue {host_ms:.2f} ms/step")
+    print(f"{nm} B={B} Tf={Tf} [{MODE}]{' +Adam' if WITH_OPT else ''}{' chain' if CHAIN else ''}{' dropout 0.5' if DROP else ''}: fwd+bwd {ms:.2f} ms/step, {B*Tp/ms/1e3:.2f} Mpos/s, ~{2*3*macs_fwd/ms/1e9:.1f} TFLOP/s (3x fwd flops); host issue {host_ms:.2f} ms/step")
