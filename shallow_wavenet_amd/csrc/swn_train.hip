@@ -1004,6 +1004,20 @@ namespace {
 // The sums over channels and frames (g w_up per tap, g b_up) stay in registers and leave as one atomic per tap and
 // workgroup.  (One workgroup per (frame, channel, utterance) with one atomic per thread: 32 M atomics onto 110 addresses
 // at the run.sh geometry - 14 ms of a 47 ms step.)
+// dropout mode: the masked input of a layer, once, as a plain tensor - the contraction kernels then run their fast forms
+// (the masked-operand forms of the 64 x 64 kernels cost 2.6 + 1.7 ms per masked layer at the run.sh geometry, the fast forms 0.3 each)
+__global__ __launch_bounds__(256) void mask_mul_kernel(const float* __restrict__ x, long x_sb, const float* __restrict__ m,
+                                                       float* __restrict__ out, long n_per_b) {
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const int b = blockIdx.y;
+    if (i >= n_per_b) return;
+    const float* xp = x + (size_t)b * x_sb + i;
+    const float* mp = m + (size_t)b * n_per_b + i;
+    float* op = out + (size_t)b * n_per_b + i;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) if (i + e < n_per_b) op[e] = xp[e] * mp[e];
+}
+
 constexpr int XM_CC = 32;
 __global__ __launch_bounds__(256) void xm_bwd_kernel(const float* __restrict__ dxm, const float* __restrict__ drop_x,
                                                      const float* __restrict__ C, const float* __restrict__ P, size_t wup,
@@ -1162,6 +1176,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const float* xm = r1 + r64((size_t)B * O1 * Tp);
     const float* gx = xm + r64((size_t)B * g.A0 * Tx);
     float* dxm = dfe + r64(fe_tot * B * n_frames);
+    float* hmask = dxm + r64((size_t)B * g.A0 * Tx);               // dropout mode only: masked input of a layer (B, H, Tp)
     if (hs_bf16) {                                     // compact layout: none of the fp32 sample-rate scratch exists
         dcond = work;
         dfe = dcond + r64((size_t)B * n_frames * g.N);
@@ -1216,10 +1231,15 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;
         ga.in_mul = in_mul;
         const float* Wd = packed + y.wd + (size_t)l * H2 * g.K * g.Hp;                 // [o2][tap][i]
+        const float* xin = hs + (size_t)l * H * Tp; long xin_sb = hsb;                 // the layer's input as the GEMMs read it
+        if (in_mul) {
+            const long npb = (long)H * Tp;
+            hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)((npb / 4 + 255) / 256 + 1), B), dim3(256), 0, st, xin, hsb, in_mul, hmask, npb);
+            xin = hmask; xin_sb = npb;
+        }
         {   // a = Wd (*) h_{l-1}   (bias added in the gate kernel)
-            TimeGemm t = {Wd, (long)g.K * g.Hp, g.Hp, 1, hs + (size_t)l * H * Tp, hsb, Tp, 1, a_da, (long)H2 * Tp, Tp, nullptr, 0, 0,
+            TimeGemm t = {Wd, (long)g.K * g.Hp, g.Hp, 1, xin, xin_sb, Tp, 1, a_da, (long)H2 * Tp, Tp, nullptr, 0, 0,
                           H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
-            t.xmul = in_mul; t.xm_sb = (long)H * Tp; t.xm_sc = Tp;
             launch_time(t, B, st);
         }
         {
@@ -1228,10 +1248,9 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             else hipLaunchKernelGGL(gate_bwd_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, ga);
         }
         {   // gWd += da X^T (taps shifted back), gbd += rowsum(da)
-            ReduceGemm r = {a_da, (long)H2 * Tp, Tp, 1, hs + (size_t)l * H * Tp, hsb, Tp, 1,
+            ReduceGemm r = {a_da, (long)H2 * Tp, Tp, 1, xin, xin_sb, Tp, 1,
                             gpacked + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, gpacked + y.bd + (size_t)l * H2,
                             H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
-            r.qmul = in_mul; r.qm_sb = (long)H * Tp; r.qm_sc = Tp;
             launch_reduce(r, B, st);
         }
         {   // dh_{l-1} += Wd^T (*) da  (taps shifted forward): A(m=i, tap, c=o2) = Wd[o2][tap][i]
@@ -1347,7 +1366,8 @@ extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch
     const size_t base = swn_backward_work_floats(d, batch, n_frames);
     if (!base) return 0;
     const long T = (long)n_frames * g.U;
-    return base + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg)));
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
+    return base + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg))) + r64((size_t)batch * g.H * Tp);
 }
 
 extern "C" int swn_backward_drop(const swn_net_desc* d, const float* packed, const float* aux, const float* fe_work,
