@@ -265,7 +265,8 @@ int    swn_backward_drop(const swn_net_desc* d, const float* packed_dev, const f
  * mode 1: mixed precision - the same fp32 tensors in HBM, operands rounded to bf16 on their way into LDS,
  *         v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what torch.autocast(bfloat16) would do to the
  *         reference's conv backward); gradients agree with mode 0 to ~1e-2 relative per tensor.
- * Applies to swn_backward, swn_backward_drop and the sample-rate in_x GEMM of swn_forward_drop. */
+ * Applies to swn_backward, swn_backward_drop and to swn_forward_drop (its sample-rate in_x GEMM and, per layer, the dilated
+ * conv as a bf16-operand GEMM followed by an element-wise gate kernel instead of the fused exact-fp32 layer kernel). */
 int    swn_train_set_precision(int mode);
 int    swn_train_get_precision(void);
 /* gradient of swn_laplace_head: grads wrt mu / b / logb / a (time-major, any may be NULL) -> grad wrt raw */

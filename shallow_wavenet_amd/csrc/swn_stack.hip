@@ -291,6 +291,10 @@ __global__ __launch_bounds__(256) void xm_fwd_kernel(const float* __restrict__ C
 
 }  // namespace
 
+// gated layers of the dropout-mode forward in the mixed-precision mode (csrc/swn_train.hip)
+int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const float* packed, const void* audio, const float* gx,
+                                  const float* const* drop_h, float* hs, float* a_scr, float* hmask, int B, int n_frames, int Tp,
+                                  hipStream_t st);
 // sample-rate in_x of every layer over the masked conditioning (csrc/swn_train.hip: generic time GEMM)
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
                           int B, int Tx, int Tp, hipStream_t st);
@@ -349,6 +353,15 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a);
     }
+    if (drop && swn_train_get_precision() == 1 && g.Hp == g.H) {
+        // mixed-precision mode: bf16-operand GEMM + element-wise gate per layer; scratch after gx: a (B, 2H, Tp) | masked input (B, H, Tp)
+        const int Tx = (int)(T - a.coff);
+        float* a_scr = const_cast<float*>(a.gx) + r64((size_t)batch * g.L * 2 * g.H * Tp);
+        float* hmask = a_scr + r64((size_t)batch * 2 * g.H * Tp);
+        (void)Tx;
+        rc = swn_train_layers_forward_drop(g, a.y, packed, audio, a.gx, drop_h, hbuf, a_scr, hmask, batch, n_frames, (int)Tp, st);
+        if (rc < 0) return rc;
+    } else
     for (int l = 0; l < g.L; ++l) {
         const dim3 grid((unsigned)(8 * ((tb64 * batch + 7) / 8) * ((g.H + 31) / 32)));
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;      // layer l-1's output was dropped
@@ -384,7 +397,9 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
     const long T = (long)n_frames * g.U;
     const int coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
-    return base + r64((size_t)batch * g.A0 * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp);
+    // xm | gx | (mixed-precision forward) gate pre-activations of one layer | masked input of one layer
+    return base + r64((size_t)batch * g.A0 * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
+           r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
 }
 
 extern "C" int swn_forward_drop(const swn_net_desc* d, const float* packed, const float* fe_work, const void* audio,

@@ -1101,6 +1101,65 @@ int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int 
     return swn_launch_status("swn_bf16_work_to_f32");
 }
 
+// Gated layers of the dropout-mode FORWARD in the mixed-precision mode: per layer the dilated conv as the bf16-operand time
+// GEMM (the kernel the backward recomputes it with) on the masked input, then the gate / highway element-wise
+// (cswnv_shift1.py:269-278 with the sample-rate in_x products `gx`).  The fp32 parity kernel tf_layer_kernel (exact-fp32
+// MFMA, 1.6 ms per layer at the run.sh geometry) stays the forward of the fp32 mode.
+namespace {
+template <int KIND>
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const GateBwd a, float* __restrict__ hs_out) {
+    const SwnGeom& g = a.g;
+    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (t >= a.Tp) return;
+    const int H = g.H, H2 = 2 * g.H, l = a.l;
+    const float* P = a.P;
+    const size_t hb = ((size_t)b * (g.L + 1)) * H * a.Tp;
+    const float im = a.in_mul ? a.in_mul[((size_t)b * H + o) * a.Tp + t] : 1.f;
+    const float hprev = a.hs[hb + ((size_t)l * H + o) * a.Tp + t] * im;
+    const float* gr = a.gx + (((size_t)b * g.L + l) * H2) * a.Tp + t;
+    float gz = gr[(size_t)o * a.Tp] + P[a.y.bxr + (size_t)l * H2 + o];
+    float gc = gr[(size_t)(H + o) * a.Tp] + P[a.y.bxr + (size_t)l * H2 + H + o];
+    if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
+        int idx = reinterpret_cast<const int*>(a.audio)[(size_t)b * a.Tp + t] % g.Q; idx = idx < 0 ? idx + g.Q : idx;
+        const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
+        gz += wa[o]; gc += wa[H + o];
+    }
+    const float sz = a.a_da[((size_t)b * H2 + o) * a.Tp + t] + P[a.y.bd + (size_t)l * H2 + o];
+    const float sc = a.a_da[((size_t)b * H2 + H + o) * a.Tp + t] + P[a.y.bd + (size_t)l * H2 + H + o];
+    const float z = sigm(gz * sz), c = tanhf(gc * sc);
+    hs_out[hb + ((size_t)(l + 1) * H + o) * a.Tp + t] = (1.f - z) * c + z * hprev;
+}
+}  // namespace
+
+int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const float* packed, const void* audio, const float* gx,
+                                  const float* const* drop_h, float* hs, float* a_scr, float* hmask, int B, int n_frames, int Tp,
+                                  hipStream_t st) {
+    GateBwd ga;
+    ga.g = g; ga.y = y; ga.P = packed; ga.cond = nullptr; ga.audio = audio; ga.hs = hs; ga.dhs = nullptr; ga.a_da = a_scr;
+    ga.dgx = nullptr; ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
+    ga.gx = gx; ga.gwxa = nullptr;
+    const int H = g.H, H2 = 2 * g.H;
+    const long hsb = (long)(g.L + 1) * H * Tp;
+    for (int l = 0; l < g.L; ++l) {
+        ga.l = l;
+        const float* in_mul = l > 0 ? drop_h[l - 1] : nullptr;
+        ga.in_mul = in_mul;
+        const float* xin = hs + (size_t)l * H * Tp; long xin_sb = hsb;
+        if (in_mul) {
+            const long npb = (long)H * Tp;
+            hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)((npb / 4 + 255) / 256 + 1), B), dim3(256), 0, st, xin, hsb, in_mul, hmask, npb);
+            xin = hmask; xin_sb = npb;
+        }
+        TimeGemm t = {packed + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, xin, xin_sb, Tp, 1, a_scr, (long)H2 * Tp, Tp,
+                      nullptr, 0, 0, H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
+        launch_time(t, B, st);
+        const dim3 grid((Tp + 255) / 256, H, B);
+        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(gate_fwd_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, ga, hs);
+        else hipLaunchKernelGGL(gate_fwd_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, ga, hs);
+    }
+    return SWN_OK;
+}
+
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
                           int B, int Tx, int Tp, hipStream_t st) {
     const int H2 = 2 * g.H;

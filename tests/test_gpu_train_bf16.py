@@ -173,9 +173,18 @@ def test_dropout_gradients_bf16_mode(gpu_ok, name):
     got = _grads(m)
     ref = {k: d[f"grad_{k}"].astype(np.float64) for k in got if f"grad_{k}" in d}
     assert ref
-    # forward AND backward rounded: the smallest tensors (norm 5e-3) sit at 3-5 %; the floor covers the scalar
-    # upsampler bias, a sum of cancelling terms of magnitude 2e-4
-    _close(name, got, ref, tol=6e-2, floor=5e-5)
+    # forward AND backward rounded (since the layer GEMMs of the dropout-mode forward run on bf16 operands too, like the
+    # forward without dropout): the smallest tensors (norm 5e-3) sit at 3-5 %; the floor covers the scalar upsampler bias,
+    # a sum of cancelling terms - 1e-3 of the largest tensor norm, the rule of test_full_size_gradients_bf16_mode
+    big = max(np.linalg.norm(v.ravel()) for v in ref.values())
+    scalar = "upsampling.conv.bias"      # = sum_{l,o} g b_inx[l][o] * sum_c W_inx[l][o][c] + sum of the masked conditioning gradient:
+    #                                      terms of either sign two orders above their sum; each carries the bf16 rounding
+    # (6e-2 while only the sample-rate in_x product of the forward was rounded; with the six layer GEMMs rounded as well the
+    #  tensors at the bottom of the stack - wav_conv, causal - reach 7 % on this 32-channel net: 1e-1)
+    _close(name, {k: v for k, v in got.items() if k != scalar}, {k: v for k, v in ref.items() if k != scalar}, tol=1e-1,
+           floor=max(5e-5, 1e-3 * big))
+    if scalar in ref:
+        assert abs(got[scalar].item() - ref[scalar].item()) <= 5e-3 * big, (name, got[scalar], ref[scalar], big)
 
 
 def test_softmax_run_sh_geometry_bf16_mode(gpu_ok):
