@@ -150,6 +150,11 @@ static inline __host__ void swn_make_layout(const SwnGeom* g, SwnLayout* y) {
     y->total = o;
 }
 
+// dropout mode in the mixed-precision mode: does swn_forward_drop run the gated layers and the two wide head layers on
+// bf16 operands (and keep the gate pre-activations for swn_backward_drop)?  The same classes as the bf16 forward without
+// dropout (H a multiple of 64): smaller nets keep the exact-fp32 forward, only their contractions of the backward are rounded.
+static inline __host__ bool swn_drop_bf16_forward(const SwnGeom* g) { return g->Hp == g->H && (g->H % 64) == 0; }
+
 // number of state_dict tensors in reference order (shallow_wavenet_amd/config.py param_shapes)
 static inline __host__ int swn_tensor_count(const SwnGeom* g) {
     return 2 + 2 * g->auxl + 2 + (g->conv2d ? 2 : 0) + (g->wav ? 2 : 0) + 2 + 6 * g->L + 4;

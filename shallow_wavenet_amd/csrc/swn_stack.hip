@@ -291,6 +291,8 @@ __global__ __launch_bounds__(256) void xm_fwd_kernel(const float* __restrict__ C
 
 }  // namespace
 
+// relu(skip), relu(out_1) from the hidden states in `work` through the contraction kernels of the training mode (csrc/swn_train.hip)
+int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st);
 // gated layers of the dropout-mode forward in the mixed-precision mode (csrc/swn_train.hip)
 int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const float* packed, const void* audio, const float* gx,
                                   const float* const* drop_h, float* hs, float* a_scr, float* hmask, int B, int n_frames, int Tp,
@@ -353,12 +355,12 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a);
     }
-    if (drop && swn_train_get_precision() == 1 && g.Hp == g.H) {
-        // mixed-precision mode: bf16-operand GEMM + element-wise gate per layer; scratch after gx: a (B, 2H, Tp) | masked input (B, H, Tp)
-        const int Tx = (int)(T - a.coff);
+    if (drop && swn_train_get_precision() == 1 && swn_drop_bf16_forward(&g)) {
+        // mixed-precision mode: bf16-operand GEMM + element-wise gate per layer; after gx in the work buffer: the gate
+        // pre-activations of every layer (B, 2H, Tp) x L - kept, the backward of the same mode reads them instead of
+        // recomputing - | masked input of one layer (B, H, Tp)
         float* a_scr = const_cast<float*>(a.gx) + r64((size_t)batch * g.L * 2 * g.H * Tp);
-        float* hmask = a_scr + r64((size_t)batch * 2 * g.H * Tp);
-        (void)Tx;
+        float* hmask = a_scr + (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp);
         rc = swn_train_layers_forward_drop(g, a.y, packed, audio, a.gx, drop_h, hbuf, a_scr, hmask, batch, n_frames, (int)Tp, st);
         if (rc < 0) return rc;
     } else
@@ -371,12 +373,19 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
     const size_t hstride = (size_t)(g.L + 1) * g.H * Tp;
     // skip: one GEMM over the L concatenated (undropped) hidden states (requires Hp == H, i.e. H % 4 == 0)
     if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
+    if (drop && swn_train_get_precision() == 1 && !hs && swn_drop_bf16_forward(&g)) {
+        // mixed-precision mode: the two wide 1x1 layers as bf16-operand time GEMMs with bias + relu epilogues (0.5 ms each as
+        // exact-fp32 gemm_wx at the run.sh geometry); out_2 (<= 16 rows) stays below
+        rc = swn_train_head_acts(g, packed, work, batch, Tp, st);
+        if (rc < 0) return rc;
+    } else {
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.S + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.wsk, g.L * g.Hp, packed + a.y.bsk, hbuf + (size_t)g.H * Tp, hstride,
                        skipb, (size_t)g.S * Tp, g.S, g.L * g.H, (int)Tp, 1);
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.O1 + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.w1, g.Sp, packed + a.y.b1, skipb, (size_t)g.S * Tp,
                        o1b, (size_t)g.O1 * Tp, g.O1, g.S, (int)Tp, 1);
+    }
     hipLaunchKernelGGL(gemm_wx_kernel, dim3(tb64, (g.NO + 63) / 64, batch), dim3(256), 0, st,
                        packed + a.y.w2, g.O1p, packed + a.y.b2, o1b, (size_t)g.O1 * Tp,
                        out, (size_t)g.NO * Tp, g.NO, g.O1, (int)Tp, 0);
@@ -397,9 +406,9 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
     const long T = (long)n_frames * g.U;
     const int coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
-    // xm | gx | (mixed-precision forward) gate pre-activations of one layer | masked input of one layer
+    // xm | gx | (mixed-precision forward) gate pre-activations of every layer | masked input of one layer
     return base + r64((size_t)batch * g.A0 * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
-           r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
+           (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
 }
 
 extern "C" int swn_forward_drop(const swn_net_desc* d, const float* packed, const float* fe_work, const void* audio,

@@ -676,6 +676,7 @@ struct GateBwd {
     const float* gx;       // (B, L, 2H, Tp) sample-rate in_x products (no bias) of the masked conditioning
     const float* in_mul;   // (B, H, Tp) mask on this layer's INPUT h_{l-1}: it was the dropped output of layer l-1
     float* gwxa;           // softmax audio_in: gradient of the one-hot columns of in_x, [L][Q][2H] (packed wxa section)
+    const float* a_in;     // gate pre-activations to read (null: a_da, where the recompute GEMM just left them)
 };
 
 template <int KIND>
@@ -714,7 +715,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
         const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
         gz += wa[o]; gc += wa[H + o];
     }
-    const float sz = *az + P[a.y.bd + (size_t)l * H2 + o], sc = *ac + P[a.y.bd + (size_t)l * H2 + H + o];
+    const float* ain = a.a_in ? a.a_in : a.a_da;
+    const float sz = ain[((size_t)b * H2 + o) * a.Tp + t] + P[a.y.bd + (size_t)l * H2 + o];
+    const float sc = ain[((size_t)b * H2 + H + o) * a.Tp + t] + P[a.y.bd + (size_t)l * H2 + H + o];
     const float z = sigm(gz * sz), c = tanhf(gc * sc);
     const float dz = dh * (hprev - c) * z * (1.f - z);      // d/d(gz*sz)
     const float dc = dh * (1.f - z) * (1.f - c * c);        // d/d(gc*sc)
@@ -1137,7 +1140,7 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
     GateBwd ga;
     ga.g = g; ga.y = y; ga.P = packed; ga.cond = nullptr; ga.audio = audio; ga.hs = hs; ga.dhs = nullptr; ga.a_da = a_scr;
     ga.dgx = nullptr; ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
-    ga.gx = gx; ga.gwxa = nullptr;
+    ga.gx = gx; ga.gwxa = nullptr; ga.a_in = nullptr;
     const int H = g.H, H2 = 2 * g.H;
     const long hsb = (long)(g.L + 1) * H * Tp;
     for (int l = 0; l < g.L; ++l) {
@@ -1150,7 +1153,9 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
             hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)((npb / 4 + 255) / 256 + 1), B), dim3(256), 0, st, xin, hsb, in_mul, hmask, npb);
             xin = hmask; xin_sb = npb;
         }
-        TimeGemm t = {packed + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, xin, xin_sb, Tp, 1, a_scr, (long)H2 * Tp, Tp,
+        float* al = a_scr + (size_t)l * r64((size_t)B * H2 * Tp);          // this layer's slot (kept for the backward)
+        ga.a_da = al;
+        TimeGemm t = {packed + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, xin, xin_sb, Tp, 1, al, (long)H2 * Tp, Tp,
                       nullptr, 0, 0, H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
         launch_time(t, B, st);
         const dim3 grid((Tp + 255) / 256, H, B);
@@ -1234,6 +1239,10 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     size_t fe_tot = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fe_tot += g.aux_cout[i];
     const float* xm = r1 + r64((size_t)B * O1 * Tp);
     const float* gx = xm + r64((size_t)B * g.A0 * Tx);
+    // dropout mode in the mixed-precision mode: swn_forward_drop of the same mode kept every layer's gate pre-activations
+    // behind gx (the arithmetic mode must not change between a forward and its backward)
+    const float* saved_a = (drop && g_train_bf16.load(std::memory_order_relaxed) == 1 && !hs_opt && swn_drop_bf16_forward(&g))
+                               ? gx + r64((size_t)B * L * H2 * Tp) : nullptr;
     float* dxm = dfe + r64(fe_tot * B * n_frames);
     float* hmask = dxm + r64((size_t)B * g.A0 * Tx);               // dropout mode only: masked input of a layer (B, H, Tp)
     if (hs_bf16) {                                     // compact layout: none of the fp32 sample-rate scratch exists
@@ -1296,7 +1305,9 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             hipLaunchKernelGGL(mask_mul_kernel, dim3((unsigned)((npb / 4 + 255) / 256 + 1), B), dim3(256), 0, st, xin, hsb, in_mul, hmask, npb);
             xin = hmask; xin_sb = npb;
         }
-        {   // a = Wd (*) h_{l-1}   (bias added in the gate kernel)
+        ga.a_in = nullptr;
+        if (saved_a) ga.a_in = saved_a + (size_t)l * r64((size_t)B * H2 * Tp);   // the forward of the same mode kept them
+        else {   // a = Wd (*) h_{l-1}   (bias added in the gate kernel)
             TimeGemm t = {Wd, (long)g.K * g.Hp, g.Hp, 1, xin, xin_sb, Tp, 1, a_da, (long)H2 * Tp, Tp, nullptr, 0, 0,
                           H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
             launch_time(t, B, st);

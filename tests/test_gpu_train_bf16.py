@@ -173,18 +173,45 @@ def test_dropout_gradients_bf16_mode(gpu_ok, name):
     got = _grads(m)
     ref = {k: d[f"grad_{k}"].astype(np.float64) for k in got if f"grad_{k}" in d}
     assert ref
-    # forward AND backward rounded (since the layer GEMMs of the dropout-mode forward run on bf16 operands too, like the
-    # forward without dropout): the smallest tensors (norm 5e-3) sit at 3-5 %; the floor covers the scalar upsampler bias,
-    # a sum of cancelling terms - 1e-3 of the largest tensor norm, the rule of test_full_size_gradients_bf16_mode
-    big = max(np.linalg.norm(v.ravel()) for v in ref.values())
-    scalar = "upsampling.conv.bias"      # = sum_{l,o} g b_inx[l][o] * sum_c W_inx[l][o][c] + sum of the masked conditioning gradient:
-    #                                      terms of either sign two orders above their sum; each carries the bf16 rounding
-    # (6e-2 while only the sample-rate in_x product of the forward was rounded; with the six layer GEMMs rounded as well the
-    #  tensors at the bottom of the stack - wav_conv, causal - reach 7 % on this 32-channel net: 1e-1)
-    _close(name, {k: v for k, v in got.items() if k != scalar}, {k: v for k, v in ref.items() if k != scalar}, tol=1e-1,
-           floor=max(5e-5, 1e-3 * big))
-    if scalar in ref:
-        assert abs(got[scalar].item() - ref[scalar].item()) <= 5e-3 * big, (name, got[scalar], ref[scalar], big)
+    # these 32-channel nets keep the exact-fp32 forward (only H % 64 == 0 nets run the dropout-mode forward on bf16
+    # operands, see test_full_size_dropout_step_bf16_mode); the sample-rate in_x product and the backward are rounded: the
+    # smallest tensors (norm 5e-3) sit at 3-5 %; the floor covers the scalar upsampler bias, a sum of cancelling terms of 2e-4
+    _close(name, got, ref, tol=6e-2, floor=5e-5)
+
+
+@pytest.mark.parametrize("shape", ["bl6", "ref6"])
+def test_full_size_dropout_step_bf16_mode(gpu_ok, shape):
+    """dropout mode (do_prob = 0.5, forward(do=True): how run.sh trains) at the full BL6 / run.sh geometries, same masks in
+    both modes: the mixed-precision mode runs the gated layers and the wide head layers of the forward on bf16 operands
+    and hands the gate pre-activations to the backward; against the fp32 mode of the same kernels, 5e-2 per tensor like
+    the step without dropout."""
+    cfg = C.bl6_laplace(1, 0) if shape == "bl6" else C.ref6_laplace(1, 4)
+    B, Tf = 3, 12
+    m = mc.CSWNV(**cfg.ctor_kwargs(), do_prob=0.5)
+    m.dropout_source = "host"            # the same masks for both modes
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True).items()})
+    m.cuda().train()
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    T = Tf * cfg.U
+    audio = (torch.rand(B, 1, T - cfg.seg, generator=torch.Generator().manual_seed(2)) * 1.8 - 0.9).cuda()
+    Tp = T - 2 * cfg.seg + 1
+    tgt = (torch.rand(B, Tp, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9).cuda()
+    out, fwd = {}, {}
+    for mode in ("fp32", "bf16"):
+        for p in m.parameters():
+            p.grad = None
+        with train_precision(mode):
+            torch.manual_seed(11)
+            res = m(aux, audio, do=True)
+            fwd[mode] = [r.detach().clone() for r in res[:3]]
+            loss = mc.LaplaceLoss()(res[0].reshape(B, Tp), res[1].reshape(B, Tp), tgt, log_b=res[2].reshape(B, Tp), log=False)
+            loss.backward()
+        out[mode] = _grads(m)
+    for a, b in zip(fwd["bf16"], fwd["fp32"]):
+        assert float((a - b).abs().max()) <= 2e-2 * max(1.0, float(b.abs().max()))
+    assert float((fwd["bf16"][0] - fwd["fp32"][0]).abs().max()) > 0, "the bf16 forward of the dropout mode did not engage"
+    big = max(np.linalg.norm(v.ravel()) for v in out["fp32"].values())
+    _close(shape, out["bf16"], out["fp32"], tol=5e-2, floor=1e-3 * big)
 
 
 def test_softmax_run_sh_geometry_bf16_mode(gpu_ok):
