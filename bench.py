@@ -251,13 +251,13 @@ def forward_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, re
     return leg
 
 
-def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps: int, kernel: str):
+def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps: int, kernel: str, do_prob: float = 0.0):
     """one full training step of the drop-in module as train_cswnv...py:700-874 runs it: forward, LaplaceLoss,
     backward (HIP kernels behind autograd), Adam step - the parameter re-pack that follows an optimizer step is
     inside the timed loop."""
     from shallow_wavenet_amd.nets import cswnv_shift1 as mc
     sd = synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True)
-    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m = mc.CSWNV(**dict(cfg.ctor_kwargs(), do_prob=do_prob))     # do_prob > 0 + forward(do=True): how run.sh trains
     m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
     m.to(dev).train()
     for p in m.scale_in.parameters():
@@ -271,7 +271,7 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
     crit = mc.LaplaceLoss()
 
     def step(with_opt=True):
-        res = m(aux, audio)
+        res = m(aux, audio, do=do_prob > 0)
         loss = crit(res[0].reshape(B, Tp), res[1].reshape(B, Tp), tgt, log_b=res[2].reshape(B, Tp), log=False)
         opt.zero_grad(set_to_none=True)
         loss.backward()
@@ -291,13 +291,13 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
         ms_nopt = _hip_timed(lambda: step(False), reps, warm=1)
     pos = B * Tp
     flops = 3 * 2.0 * stack_macs_per_position(cfg) * pos
-    leg = {"workload": name, "batch": B, "positions": pos, "precision": mode, "ms": round(ms, 3),
+    leg = {"workload": name, "batch": B, "positions": pos, "precision": mode, "do_prob": do_prob, "ms": round(ms, 3),
            "ms_forward_backward_only": round(ms_nopt, 3), "value": round(pos / (ms * 1e-3), 1), "unit": "positions/s",
            "tflops": round(flops / (ms * 1e-3) / 1e12, 2),
            "includes": "forward + LaplaceLoss + backward + Adam step + parameter re-pack, wall clock"}
     peak = MFMA_BF16_TFLOPS if mode == "bf16" else MFMA_FP32_TFLOPS
     leg["roofline"] = _mfma(flops, ms, peak, kernel=kernel, algorithmic_flops="3 x forward (2 x MAC)")
-    if mode == "bf16" and cfg.H == 64 and cfg.K == 2 and cfg.seg == 1:
+    if mode == "bf16" and cfg.H == 64 and cfg.K == 2 and cfg.seg == 1 and do_prob == 0:
         # the fused BL6 path is bound by its streams, not by the matrix cores: bytes per position of the
         # sample-rate launches - forward 128 + 6 x 256 + 776, head backward 1 800, six layer launches x 1 408, the last
         # launch 520, ten weight-gradient jobs x 512
@@ -360,6 +360,11 @@ def run_legs(dev, quick: bool = False):
         "bf16g_gemm + time_gemm_bf16t / reduce_gemm_bf16s")
     add("cfg4_ref6_step_fp32", train_leg, "cfg4 training step: REF6, 8 x 16 500, fp32 parity mode", ref6, dev, 8, 150, "fp32", 2,
         "tf_layer + time_gemm / reduce_gemm (exact-fp32 MFMA)")
+    add("cfg4_ref6_step_bf16_dropout", train_leg, "cfg4 training step as run.sh trains: REF6, 8 x 16 500, do_prob 0.5 (masks drawn on the "
+        "device), mixed precision", ref6, dev, 8, 150, "bf16", 3,
+        "time_gemm_bf16t (forward layers, in_x at sample rate) + gate_fwd / gate_bwd + reduce_gemm_bf16s", do_prob=0.5)
+    add("cfg4_bl6_step_bf16_dropout", train_leg, "the same at BL6", bl6, dev, 8, 150, "bf16", 3,
+        "time_gemm_bf16t + gate_fwd / gate_bwd + reduce_gemm_bf16s (generic chain: the fused backward has no dropout form)", do_prob=0.5)
     add("cfg4_bl6_step_bf16_b64", train_leg, "the same step at 8x the batch: BL6, 64 x 16 500, mixed precision", bl6, dev, 64, 150,
         "bf16", 3, "bf16 forward + fused backward (bl6_head_bwd / bl6_layer_bwd x 7 / bl6_wgrad) + unfold_grads")
     return legs
