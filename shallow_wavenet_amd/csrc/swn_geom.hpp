@@ -150,6 +150,11 @@ static inline __host__ void swn_make_layout(const SwnGeom* g, SwnLayout* y) {
     y->total = o;
 }
 
+// dropout mode: channel rows per utterance of the masked, upsampled conditioning xm (B, A0x, Tx): A0 rounded up to 32 with
+// zero rows, so that the sample-rate in_x GEMM (k = conditioning channel) runs whole 32-wide k-tiles (A0 = 486 took the
+// generic 64 x 64 kernel: 0.36 ms per layer at the run.sh geometry against ~0.15 for the tile-uniform form)
+static inline __host__ int swn_a0x(const SwnGeom* g) { return (g->A0 + 31) & ~31; }
+
 // dropout mode in the mixed-precision mode: does swn_forward_drop run the gated layers and the two wide head layers on
 // bf16 operands (and keep the gate pre-activations for swn_backward_drop)?  The same classes as the bf16 forward without
 // dropout (H a multiple of 64): smaller nets keep the exact-fp32 forward, only their contractions of the backward are rounded.

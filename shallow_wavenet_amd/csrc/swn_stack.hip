@@ -281,12 +281,14 @@ namespace {
 // with u + coff = f*U + j   (cswnv_shift1.py:193-195, dswnv.py:252-254)
 __global__ __launch_bounds__(256) void xm_fwd_kernel(const float* __restrict__ C, const float* __restrict__ P, size_t wup, size_t bup,
                                                      const float* __restrict__ drop_x, float* __restrict__ xm,
-                                                     int A0, int Tf, int U, int coff, int Tx) {
-    const int u = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+                                                     int A0, int A0x, int Tf, int U, int coff, int Tx) {
+    const int u = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;      // c < A0x; rows A0.. are zero padding
     if (u >= Tx) return;
+    const size_t ox = ((size_t)b * A0x + c) * Tx + u;
+    if (c >= A0) { xm[ox] = 0.f; return; }
     const int tt = u + coff, f = tt / U, j = tt - f * U;
     const size_t o = ((size_t)b * A0 + c) * Tx + u;
-    xm[o] = drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]);
+    xm[ox] = drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]);
 }
 
 }  // namespace
@@ -336,15 +338,15 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
     a.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
     a.gx = nullptr;
     if (drop) {
-        // work tail: xm (B, A0, Tx) | gx (B, L, 2H, Tp)
+        // work tail: xm (B, A0x, Tx) | gx (B, L, 2H, Tp)
         const int Tx = (int)(T - a.coff);
         float* xm = o1b + r64((size_t)batch * g.O1 * Tp);
-        float* gx = xm + r64((size_t)batch * g.A0 * Tx);
+        float* gx = xm + r64((size_t)batch * swn_a0x(&g) * Tx);
         size_t fe_off = (size_t)g.n_aux;                         // frame-rate activations: scaled | conv_aux layers
         for (int i = 0; i + 1 < g.auxl; ++i) fe_off += g.aux_cout[i];
         const float* C = fe_work + fe_off * (size_t)batch * n_frames;
-        hipLaunchKernelGGL(xm_fwd_kernel, dim3((Tx + 255) / 256, g.A0, batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
-                           drop_x, xm, g.A0, n_frames, g.U, a.coff, Tx);
+        hipLaunchKernelGGL(xm_fwd_kernel, dim3((Tx + 255) / 256, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
+                           drop_x, xm, g.A0, swn_a0x(&g), n_frames, g.U, a.coff, Tx);
         rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st);
         if (rc < 0) return rc;
         a.gx = gx;
@@ -407,7 +409,7 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
     const int coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     // xm | gx | (mixed-precision forward) gate pre-activations of every layer | masked input of one layer
-    return base + r64((size_t)batch * g.A0 * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
+    return base + r64((size_t)batch * swn_a0x(&g) * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
            (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
 }
 

@@ -1169,9 +1169,12 @@ int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* pac
                           int B, int Tx, int Tp, hipStream_t st) {
     const int H2 = 2 * g.H;
     for (int l = 0; l < g.L; ++l) {   // gx[b][l][o][t] = sum_{s,c} W[l][o][c*seg+s] xm[b][c][t+s]
+        // k runs over the A0x = 32-aligned rows of xm: beyond A0 the activations are zero rows and the weights whatever
+        // follows in the packed buffer (padding, then the next row: finite), so the products vanish
+        const int A0x = swn_a0x(&g);
         TimeGemm t = {packed + y.wx + (size_t)l * g.seg * H2 * g.A0p, g.A0p, (long)H2 * g.A0p, 1,
-                      xm, (long)g.A0 * Tx, Tx, 1, gx + (size_t)l * H2 * Tp, (long)g.L * H2 * Tp, Tp, nullptr, 0, 0,
-                      H2, g.seg, g.A0, Tp, 1, 0, 1, 0};
+                      xm, (long)A0x * Tx, Tx, 1, gx + (size_t)l * H2 * Tp, (long)g.L * H2 * Tp, Tp, nullptr, 0, 0,
+                      H2, g.seg, A0x, Tp, 1, 0, 1, 0};
         t.XT = Tx;
         launch_time(t, B, st);
     }
@@ -1238,7 +1241,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const int Tx = (int)(T - coff);
     size_t fe_tot = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fe_tot += g.aux_cout[i];
     const float* xm = r1 + r64((size_t)B * O1 * Tp);
-    const float* gx = xm + r64((size_t)B * g.A0 * Tx);
+    const float* gx = xm + r64((size_t)B * swn_a0x(&g) * Tx);
     // dropout mode in the mixed-precision mode: swn_forward_drop of the same mode kept every layer's gate pre-activations
     // behind gx (the arithmetic mode must not change between a forward and its backward)
     const float* saved_a = (drop && g_train_bf16.load(std::memory_order_relaxed) == 1 && !hs_opt && swn_drop_bf16_forward(&g))
@@ -1339,7 +1342,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
             {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
-                ReduceGemm r = {dgx, (long)H2 * Tp, Tp, 1, xm, (long)g.A0 * Tx, Tx, 1,
+                ReduceGemm r = {dgx, (long)H2 * Tp, Tp, 1, xm, (long)swn_a0x(&g) * Tx, Tx, 1,
                                 gpacked + y.wx + (size_t)l * g.seg * H2 * g.A0p, g.A0p, (long)H2 * g.A0p, 1,
                                 gpacked + y.bxr + (size_t)l * H2, H2, g.seg, g.A0, Tp, 1, 0, 1, 0};
                 r.QT = Tx;
