@@ -218,21 +218,44 @@ def batch_loss(model, criterion_laplace, criterion_lsd, batch_h, batch_x, target
     def draw(shape):
         return torch.empty(shape).uniform_(-0.4999, 0.5, generator=eps_generator).to(mus.device)
 
-    def spectral(sample, trg):
+    # The spectral terms (train_cswnv...py:786-868).  The reference runs, per segment j and per FFT size, two `torch.stft`s
+    # and two LSDloss calls and keeps a term only `if not torch.isinf(v) and not torch.isnan(v)`: 340 small STFTs, ~2 400
+    # tiny launches and 170 device->host round trips per chunk at run.sh's seg = 5 / 17 sizes - on this GPU that, not the
+    # network (2-3 ms), is the chunk time (34 ms).  Same numbers with the segments batched: per FFT size ONE stft over
+    # the 2 x seg stacked signals (rows are independent), the two LSDloss formulas (cswnv_shift1.py:456-476) evaluated per
+    # row, and the finite-term selection as masks on the device: a term that is not finite contributes 0 to the sum and 0
+    # to the count; mean = sum / count, "no term at all" (the reference's empty list) is count == 0.
+    def spectral(samples, targets):
+        """samples / targets: lists of R equally long signals -> ((l1_mean[R], l1_count[R]), (lsd_mean[R], lsd_count[R]))
+        or (None, None) when no FFT size applies"""
+        R = len(samples)
+        sig = torch.stack(list(samples) + list(targets))                      # (2R, T)
         l1, lsd = [], []
         for n_fft, win in zip(fft_facts, hann_win):
             if feat_len > n_fft // 2:
-                so, st = _stft(sample, n_fft, win), _stft(trg, n_fft, win)
-                v = criterion_lsd(so, st, LSD=False, L2=False)
-                if not torch.isinf(v) and not torch.isnan(v):
-                    l1.append(v)
-                v = criterion_lsd(so, st)
-                if not torch.isinf(v) and not torch.isnan(v):
-                    lsd.append(v)
-        return l1, lsd
+                sp = _stft(sig, n_fft, win)                                   # (2R, F, N, 2)
+                so, st = sp[:R], sp[R:]
+                l1.append(torch.abs(so - st).mean(dim=(1, 2, 3)))             # LSDloss(LSD=False, L2=False)
+                pow_x, pow_y = torch.sum(so ** 2, -1), torch.sum(st ** 2, -1)
+                lsd.append(torch.sqrt(torch.mean((10 * (torch.log10(pow_x) - torch.log10(pow_y))) ** 2, 1)).mean(1))   # LSDloss()
+        if not l1:
+            return None, None
+
+        def masked_mean(rows):                                                # [K] x (R,) -> mean over the finite of the K terms
+            v = torch.stack(rows, 1)                                          # (R, K)
+            ok = torch.isfinite(v)
+            n = ok.sum(1)
+            return torch.where(ok, v, torch.zeros_like(v)).sum(1) / n.clamp(min=1), n
+        return masked_mean(l1), masked_mean(lsd)
+
+    def mean_of_present(mean_r, count_r):
+        """mean over the segments whose own list was not empty (count > 0), like the reference's `if l1:` append"""
+        has = count_r > 0
+        k = has.sum()
+        return torch.where(has, mean_r, torch.zeros_like(mean_r)).sum() / k.clamp(min=1), k
 
     if seg > 1:
-        nll, err, l1_all, lsd_all = [], [], [], []
+        nll, err, samples, targets = [], [], [], []
         for i in range(seg):
             mus_i, bn_i = mus[:, i], bs_noclip[:, i]
             trg_i = target[i:-(seg - (i + 1))] if i + 1 < seg else target[i:]
@@ -240,23 +263,23 @@ def batch_loss(model, criterion_laplace, criterion_lsd, batch_h, batch_x, target
             eps = draw(mus_i.shape)
             sample = mus_i - bn_i * eps.sign() * torch.log1p(-2 * eps.abs())
             err.append(torch.mean(torch.abs(sample - trg_i)))
-            l1, lsd = spectral(sample, trg_i)
-            if l1:
-                l1_all.append(torch.mean(torch.stack(l1)))
-            if lsd:
-                lsd_all.append(torch.mean(torch.stack(lsd)))
+            samples.append(sample); targets.append(trg_i)
         loss_laplace = torch.mean(torch.stack(nll))
-        loss = loss_laplace + (torch.mean(torch.stack(l1_all)) if l1_all else 0)
-        loss_lsd = torch.mean(torch.stack(lsd_all)) if lsd_all else None
         loss_err = torch.mean(torch.stack(err))
     else:
         loss_laplace = criterion_laplace(mus, bs, target, log_b=log_bs)
         eps = draw(mus.shape)
         sample = mus - bs_noclip * eps.sign() * torch.log1p(-2 * eps.abs())
         loss_err = torch.mean(torch.abs(sample - target))
-        l1, lsd = spectral(sample, target)
-        loss = loss_laplace + (torch.mean(torch.stack(l1)) if l1 else 0)
-        loss_lsd = torch.mean(torch.stack(lsd)) if lsd else None
+        samples, targets = [sample], [target]
+    l1_terms, lsd_terms = spectral(samples, targets)
+    loss, loss_lsd = loss_laplace, None
+    if l1_terms is not None:
+        loss = loss_laplace + mean_of_present(*l1_terms)[0]                 # no finite term anywhere: + 0, like `else 0`
+        lsd_mean, lsd_k = mean_of_present(*lsd_terms)
+        # "no LSD figure" (every term not finite) is reported as None: the one host decision left, taken where the caller
+        # is about to call .item() for its log line anyway
+        loss_lsd = lsd_mean if int(lsd_k.item()) > 0 else None
     return loss, loss_laplace, loss_lsd, loss_err
 
 
