@@ -19,8 +19,8 @@ struct PackArgs {
 
 enum { SEC_COPY = 0, SEC_CAUSAL, SEC_INX, SEC_INX_BIAS, SEC_DIL, SEC_SKIP, SEC_OUT, SEC_COUNT };
 
-__device__ static inline void copy_n(float* dst, const float* src, size_t n, size_t tid, size_t nth) {
-    for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
+__device__ static inline void copy_n(float* dst, const float* src, size_t n, unsigned tid, unsigned nth) {
+    for (unsigned i = tid; i < n; i += nth) dst[i] = src[i];
 }
 
 // effective in_x weight W_eff[o][c*seg+s] of layer l (the (seg,1) Conv2d folded in, cswnv_shift1.py:196-198)
@@ -41,8 +41,9 @@ __device__ static inline float inx_eff(const PackArgs& a, int l, int o, int c, i
 __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __restrict__ out) {
     const SwnGeom& g = a.g;
     const SwnLayout& y = a.y;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nth = (size_t)gridDim.x * blockDim.x;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;      // 32-bit element indices: every section is far below 2^31
+    // (64-bit divisions per element made these two kernels 160-250 us at the run.sh geometry)
+    const unsigned nth = gridDim.x * blockDim.x;
     const int H = g.H, S = g.S, K = g.K, L = g.L, seg = g.seg, Q = g.Q, H2 = 2 * g.H;
     switch (blockIdx.y) {
     case SEC_COPY: {
@@ -66,7 +67,7 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
         const float* wav_b = g.wav ? a.t[a.i_wav + 1] : nullptr;
         const int cin = g.wav ? H : (g.kind == SWN_KIND_LAPLACE ? 1 : Q);
         if (g.kind == SWN_KIND_LAPLACE) {
-            for (size_t e = tid; e < (size_t)K * H; e += nth) {
+            for (unsigned e = tid; e < (size_t)K * H; e += nth) {
                 const int k = (int)(e / H), o = (int)(e % H);
                 if (g.wav) {
                     double sv = 0, sc = 0;
@@ -81,8 +82,8 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
                 }
             }
         } else {
-            for (size_t e = tid; e < (size_t)K * Q * H; e += nth) {
-                const int o = (int)(e % H), q = (int)((e / H) % Q), k = (int)(e / ((size_t)H * Q));
+            for (unsigned e = tid; e < (size_t)K * Q * H; e += nth) {
+                const int o = (int)(e % H), q = (int)((e / H) % Q), k = (int)(e / (unsigned)(H * Q));
                 float v;
                 if (g.wav) {
                     double s = 0;
@@ -99,17 +100,17 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
     }
     case SEC_INX: {     // stacked rows of the frame-rate GEMM (+ the one-hot columns of audio_in)
         const size_t n = (size_t)L * seg * H2 * g.A0;
-        for (size_t e = tid; e < n; e += nth) {
+        for (unsigned e = tid; e < n; e += nth) {
             const int c = (int)(e % g.A0);
-            size_t r = e / g.A0;
+            unsigned r = e / g.A0;
             const int o = (int)(r % H2); r /= H2;
             const int s = (int)(r % seg), l = (int)(r / seg);
             out[y.wx + ((size_t)(l * seg + s) * H2 + o) * g.A0p + c] = inx_eff(a, l, o, c, s);
         }
         if (g.audio_in) {
             const int A = g.A0 * seg + Q;
-            for (size_t e = tid; e < (size_t)L * Q * H2; e += nth) {
-                const int o = (int)(e % H2), q = (int)((e / H2) % Q), l = (int)(e / ((size_t)H2 * Q));
+            for (unsigned e = tid; e < (size_t)L * Q * H2; e += nth) {
+                const int o = (int)(e % H2), q = (int)((e / H2) % Q), l = (int)(e / (unsigned)(H2 * Q));
                 out[y.wxa + e] = a.t[a.i_inx + 2 * l][(size_t)o * A + g.A0 + q];
             }
         }
@@ -117,7 +118,7 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
     }
     case SEC_INX_BIAS: {   // bx = b + b_up * sum W_eff (c-major, s-minor, double), bxr = b (+ W_in . b2 with the Conv2d)
         const float bup = a.t[a.i_up + 1][0];
-        for (size_t e = tid; e < (size_t)L * H2; e += nth) {
+        for (unsigned e = tid; e < (size_t)L * H2; e += nth) {
             const int l = (int)(e / H2), o = (int)(e % H2);
             double bo = a.t[a.i_inx + 2 * l + 1][o], ws = 0.0;
             if (g.conv2d) {
@@ -150,15 +151,15 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
     }
     case SEC_DIL: {     // tap-major rows [l][o][k][i] (+ the register image of the BL6 decode kernel)
         const size_t n = (size_t)L * H2 * K * H;
-        for (size_t e = tid; e < n; e += nth) {
+        for (unsigned e = tid; e < n; e += nth) {
             const int i = (int)(e % H);
-            size_t r = e / H;
+            unsigned r = e / H;
             const int k = (int)(r % K); r /= K;
             const int o = (int)(r % H2), l = (int)(r / H2);
             out[y.wd + (((size_t)l * H2 + o) * K + k) * g.Hp + i] = a.t[a.i_dil + 2 * l][((size_t)o * H + i) * K + k];
         }
         if (g.bl6) {
-            for (size_t e = tid; e < (size_t)L * 512 * 32; e += nth) {
+            for (unsigned e = tid; e < (size_t)L * 512 * 32; e += nth) {
                 const int me = (int)(e % 16), r = (int)((e / 16) % 2), tt = (int)((e / 32) % 512), l = (int)(e / (32 * 512));
                 const int m = me / 4, ee = me % 4, o = tt >> 3, p = tt & 7;
                 const int j = 32 * m + 4 * p + ee, k = j / H, i = j % H;
@@ -168,14 +169,14 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
         break;
     }
     case SEC_SKIP: {    // skip 1x1s concatenated along the input axis, biases summed over layers in double
-        for (size_t e = tid; e < (size_t)S * L * H; e += nth) {
-            const int i = (int)(e % H), l = (int)((e / H) % L), c = (int)(e / ((size_t)H * L));
+        for (unsigned e = tid; e < (size_t)S * L * H; e += nth) {
+            const int i = (int)(e % H), l = (int)((e / H) % L), c = (int)(e / (unsigned)(H * L));
             const float v = a.t[a.i_skip + 2 * l][(size_t)c * H + i];
             out[y.wsk + (size_t)c * L * g.Hp + (size_t)l * g.Hp + i] = v;
             if (g.bl6)
                 out[y.wsk2 + ((((size_t)l * 4 + i / 16) * S + c) * 4 + (i % 16) / 4) * 4 + (i % 4)] = v;
         }
-        for (size_t c = tid; c < (size_t)S; c += nth) {
+        for (unsigned c = tid; c < (size_t)S; c += nth) {
             double b = 0.0;
             for (int l = 0; l < L; ++l) b += a.t[a.i_skip + 2 * l + 1][c];
             out[y.bsk + c] = (float)b;
@@ -184,13 +185,13 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
     }
     case SEC_OUT: {
         const float* w1 = a.t[a.i_out1];
-        for (size_t e = tid; e < (size_t)g.O1 * S; e += nth) {
+        for (unsigned e = tid; e < (size_t)g.O1 * S; e += nth) {
             const int c = (int)(e % S), o = (int)(e / S);
             out[y.w1 + (size_t)o * g.Sp + c] = w1[e];
             if (g.bl6) out[y.w12 + ((((size_t)(c / 16)) * g.O1 + o) * 4 + (c % 16) / 4) * 4 + (c % 4)] = w1[e];
         }
         const float* w2 = a.t[a.i_out2];
-        for (size_t e = tid; e < (size_t)g.NO * g.O1; e += nth) {
+        for (unsigned e = tid; e < (size_t)g.NO * g.O1; e += nth) {
             const int c = (int)(e % g.O1), o = (int)(e / g.O1);
             out[y.w2 + (size_t)o * g.O1p + c] = w2[e];
             if (g.bl6 && g.kind == SWN_KIND_SOFTMAX)

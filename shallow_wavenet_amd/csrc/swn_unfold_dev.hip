@@ -25,16 +25,17 @@ struct UnfoldArgs {
 
 enum { U_COPY = 0, U_INX, U_DIL, U_SKIP, U_OUT, U_CAUSAL, U_UPB, U_COUNT };
 
-__device__ inline void copy_n(float* dst, const float* src, size_t n, size_t tid, size_t nth) {
+__device__ inline void copy_n(float* dst, const float* src, size_t n, unsigned tid, unsigned nth) {
     if (!dst) return;
-    for (size_t i = tid; i < n; i += nth) dst[i] = src[i];
+    for (unsigned i = tid; i < n; i += nth) dst[i] = src[i];
 }
 
 __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, const float* __restrict__ gp) {
     const SwnGeom& g = a.g;
     const SwnLayout& y = a.y;
-    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t nth = (size_t)gridDim.x * blockDim.x;
+    const unsigned tid = blockIdx.x * blockDim.x + threadIdx.x;      // 32-bit element indices: every section is far below 2^31
+    // (64-bit divisions per element made these two kernels 160-250 us at the run.sh geometry)
+    const unsigned nth = gridDim.x * blockDim.x;
     const int H = g.H, S = g.S, K = g.K, L = g.L, seg = g.seg, Q = g.Q, H2 = 2 * g.H;
     switch (blockIdx.y) {
     case U_COPY: {
@@ -50,7 +51,7 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
             copy_n(a.o[a.i_dil + 2 * l + 1], gp + y.bd + (size_t)l * H2, H2, tid, nth);
             copy_n(a.o[a.i_skip + 2 * l + 1], gp + y.bsk, S, tid, nth);          // the packed skip bias is the sum over layers
             if (float* d = a.o[a.i_inx + 2 * l + 1])                              // d b_inx: hoisted mode + dropout mode
-                for (size_t i = tid; i < (size_t)H2; i += nth) d[i] = gp[y.bx + (size_t)l * H2 + i] + gp[y.bxr + (size_t)l * H2 + i];
+                for (unsigned i = tid; i < (size_t)H2; i += nth) d[i] = gp[y.bx + (size_t)l * H2 + i] + gp[y.bxr + (size_t)l * H2 + i];
         }
         copy_n(a.o[a.i_out1 + 1], gp + y.b1, g.O1, tid, nth);
         copy_n(a.o[a.i_out2 + 1], gp + y.b2, g.NO, tid, nth);
@@ -59,9 +60,9 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
     case U_INX: {       // d in_x.W[l][o][c*seg+s] = gwx[l][s][o][c] + gbx[l][o] * b_up  (+ the one-hot columns of audio_in)
         const float bup = a.t[a.i_up + 1][0];
         const int A = g.A0 * seg + (g.audio_in ? Q : 0), n1 = g.A0 * seg;
-        for (size_t e = tid; e < (size_t)L * H2 * A; e += nth) {
+        for (unsigned e = tid; e < (size_t)L * H2 * A; e += nth) {
             const int j = (int)(e % A);
-            size_t r = e / A;
+            unsigned r = e / A;
             const int o = (int)(r % H2), l = (int)(r / H2);
             float* d = a.o[a.i_inx + 2 * l];
             if (!d) continue;
@@ -77,9 +78,9 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
         break;
     }
     case U_DIL: {
-        for (size_t e = tid; e < (size_t)L * H2 * H * K; e += nth) {
+        for (unsigned e = tid; e < (size_t)L * H2 * H * K; e += nth) {
             const int k = (int)(e % K);
-            size_t r = e / K;
+            unsigned r = e / K;
             const int i = (int)(r % H); r /= H;
             const int o = (int)(r % H2), l = (int)(r / H2);
             if (float* d = a.o[a.i_dil + 2 * l]) d[((size_t)o * H + i) * K + k] = gp[y.wd + (((size_t)l * H2 + o) * K + k) * g.Hp + i];
@@ -87,17 +88,17 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
         break;
     }
     case U_SKIP: {
-        for (size_t e = tid; e < (size_t)L * S * H; e += nth) {
-            const int i = (int)(e % H), c = (int)((e / H) % S), l = (int)(e / ((size_t)H * S));
+        for (unsigned e = tid; e < (size_t)L * S * H; e += nth) {
+            const int i = (int)(e % H), c = (int)((e / H) % S), l = (int)(e / (unsigned)(H * S));
             if (float* d = a.o[a.i_skip + 2 * l]) d[(size_t)c * H + i] = gp[y.wsk + (size_t)c * L * g.Hp + (size_t)l * g.Hp + i];
         }
         break;
     }
     case U_OUT: {
         if (float* d = a.o[a.i_out1])
-            for (size_t e = tid; e < (size_t)g.O1 * S; e += nth) d[e] = gp[y.w1 + (e / S) * g.Sp + (e % S)];
+            for (unsigned e = tid; e < (size_t)g.O1 * S; e += nth) d[e] = gp[y.w1 + (e / S) * g.Sp + (e % S)];
         if (float* d = a.o[a.i_out2])
-            for (size_t e = tid; e < (size_t)g.NO * g.O1; e += nth) d[e] = gp[y.w2 + (e / g.O1) * g.O1p + (e % g.O1)];
+            for (unsigned e = tid; e < (size_t)g.NO * g.O1; e += nth) d[e] = gp[y.w2 + (e / g.O1) * g.O1p + (e % g.O1)];
         break;
     }
     case U_CAUSAL: {    // causal.conv.weight (H, Cin, K) and the lift wav_conv, through cv/cc (laplace) or the gather table ct
@@ -107,17 +108,17 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
             const float* gcv = gp + y.cv;
             const float* gcc = gp + y.cc;
             if (!g.wav) {
-                if (dwc) for (size_t e = tid; e < (size_t)H * K; e += nth) dwc[e] = gcv[(e % K) * H + e / K];
+                if (dwc) for (unsigned e = tid; e < (size_t)H * K; e += nth) dwc[e] = gcv[(e % K) * H + e / K];
                 break;
             }
             const float* ww = a.t[a.i_wav];
             const float* wb = a.t[a.i_wav + 1];
             if (dwc)
-                for (size_t e = tid; e < (size_t)H * H * K; e += nth) {
-                    const int k = (int)(e % K), i = (int)((e / K) % H), o = (int)(e / ((size_t)K * H));
+                for (unsigned e = tid; e < (size_t)H * H * K; e += nth) {
+                    const int k = (int)(e % K), i = (int)((e / K) % H), o = (int)(e / (unsigned)(K * H));
                     dwc[e] = gcv[k * H + o] * ww[i] + gcc[k * H + o] * wb[i];
                 }
-            for (size_t i = tid; i < (size_t)H; i += nth) {
+            for (unsigned i = tid; i < (size_t)H; i += nth) {
                 double sw = 0.0, sb = 0.0;
                 for (int o = 0; o < H; ++o)
                     for (int k = 0; k < K; ++k) {
@@ -131,8 +132,8 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
             const float* gct = gp + y.ct;                                 // [K][Q][H]
             if (!g.wav) {
                 if (dwc)
-                    for (size_t e = tid; e < (size_t)H * Q * K; e += nth) {
-                        const int k = (int)(e % K), q = (int)((e / K) % Q), o = (int)(e / ((size_t)K * Q));
+                    for (unsigned e = tid; e < (size_t)H * Q * K; e += nth) {
+                        const int k = (int)(e % K), q = (int)((e / K) % Q), o = (int)(e / (unsigned)(K * Q));
                         dwc[e] = gct[((size_t)k * Q + q) * H + o];
                     }
                 break;
@@ -140,15 +141,15 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
             const float* ww = a.t[a.i_wav];                               // (H, Q, 1)
             const float* wb = a.t[a.i_wav + 1];
             if (dwc)        // d wc[o][i][k] = sum_q gct[k][q][o] * (ww[i][q] + wb[i]);  o fastest across threads: coalesced gct reads
-                for (size_t e = tid; e < (size_t)H * H * K; e += nth) {
-                    const int o = (int)(e % H), i = (int)((e / H) % H), k = (int)(e / ((size_t)H * H));
+                for (unsigned e = tid; e < (size_t)H * H * K; e += nth) {
+                    const int o = (int)(e % H), i = (int)((e / H) % H), k = (int)(e / (unsigned)(H * H));
                     double s = 0.0;
                     const float bi = wb[i];
                     for (int q = 0; q < Q; ++q) s += (double)gct[((size_t)k * Q + q) * H + o] * (double)(ww[(size_t)i * Q + q] + bi);
                     dwc[((size_t)o * H + i) * K + k] = (float)s;
                 }
             // d ww[i][q] = sum_{k,o} gct[k][q][o] * wc[o][i][k];   d wb[i] = sum_q of the same terms (zeroed by the host, atomics)
-            for (size_t e = tid; e < (size_t)H * Q; e += nth) {
+            for (unsigned e = tid; e < (size_t)H * Q; e += nth) {
                 const int q = (int)(e % Q), i = (int)(e / Q);
                 double s = 0.0;
                 for (int k = 0; k < K; ++k)
