@@ -280,7 +280,7 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
         return loss
 
     with train_precision(mode):
-        for _ in range(2):
+        for _ in range(4):                       # the caching allocator needs a few steps to settle after the previous leg
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
