@@ -16,7 +16,8 @@ WITH_OPT = len(sys.argv) > 5 and sys.argv[5] == "opt"           # optional 5th a
 CHAIN = len(sys.argv) > 6 and sys.argv[6] == "chain"            # optional 6th argument "chain": generic per-layer backward
 FUSED_ADAM = "fused_adam" in sys.argv                            # anywhere: torch.optim.Adam(fused=True)
 DROP = 0.5 if "drop" in sys.argv else 0.0                        # anywhere "drop": do_prob = 0.5 and forward(do=True), as run.sh trains
-for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
+SEG5 = "seg5" in sys.argv                                        # anywhere "seg5": seg = 5, lpc = 4 (run.sh's own setting)
+for nm, cfg in (("BL6", C.bl6_laplace(5, 4) if SEG5 else C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(5, 4) if SEG5 else C.ref6_laplace(1, 4))):
     if ONLY and nm != ONLY:
         continue
     m = mc.CSWNV(**dict(cfg.ctor_kwargs(), do_prob=DROP))
@@ -36,8 +37,13 @@ for nm, cfg in (("BL6", C.bl6_laplace(1, 0)), ("REF6", C.ref6_laplace(1, 4))):
         if CHAIN:
             m._engine().fused_backward = False
         res = m(aux, audio, do=DROP > 0)
-        mu, b, log_b = res[0].reshape(B, Tp), res[1].reshape(B, Tp), res[2].reshape(B, Tp)
-        loss = mc.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
+        if cfg.seg > 1:      # (B, Tp, seg) outputs: NLL of every segment position against the same target value (timing only)
+            loss = mc.LaplaceLoss()(res[0], res[1], tgt[..., None].expand_as(res[0]), log_b=res[2], log=False)
+            if cfg.lpc > 0:
+                loss = loss + 0.1 * res[3].pow(2).mean()
+        else:
+            mu, b, log_b = res[0].reshape(B, Tp), res[1].reshape(B, Tp), res[2].reshape(B, Tp)
+            loss = mc.LaplaceLoss()(mu, b, tgt, log_b=log_b, log=False)
         for p in m.parameters():
             p.grad = None
         loss.backward()
