@@ -961,7 +961,11 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
             //  there; with many tiles per segment the atomics amortise and more workgroups hide the loads - measured both ways)
             const int target = mt * nt >= 4 ? 1024 : 256;
             int want = (target + mt * nt * B - 1) / (mt * nt * B);
-            const int most = (g.T + 255) / 256;
+            // a time segment is at least 256 positions, 1 024 where the gradient has many tiles: at the training drivers' own
+            // chunk (one utterance, 8 800 positions) 31 segments of 288 positions meant 31 atomics per gradient element and nine
+            // k-steps of work per workgroup (75 us per call, atomics-bound)
+            const int seg_min = mt * nt >= 16 ? 1024 : 256;
+            const int most = (g.T + seg_min - 1) / seg_min;
             if (want > most) want = most;
             if (want < 1) want = 1;
             g.TS = (((g.T + want - 1) / want) + 31) & ~31;
