@@ -249,7 +249,9 @@ int    swn_backward_bf16(const swn_net_desc* d, const float* packed_dev, const f
  *                hands to layer l+1 (its skip output is not masked), NULL where the reference does not drop
  * aux_drop acts at sample rate, so the frame-rate hoisting of in_x does not apply: in_x is evaluated as a
  * sample-rate GEMM on the masked conditioning (no cond_dev input; fe_work_dev = swn_frontend's work buffer).
- * fwd_work_dev of swn_backward_drop must be the buffer swn_forward_drop filled. */
+ * fwd_work_dev of swn_backward_drop must be the buffer swn_forward_drop filled, and the arithmetic mode
+ * (swn_train_set_precision) must be the same for both calls: in mode 1, for nets with hid_chn % 64 == 0, the forward keeps
+ * every layer's gate pre-activations in that buffer and the backward reads them instead of recomputing them. */
 size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_forward_drop(const swn_net_desc* d, const float* packed_dev, const float* fe_work_dev, const void* audio_dev,
                         int batch, int n_frames, const float* drop_x_dev, const float* const* drop_h_host,
