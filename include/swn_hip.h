@@ -239,6 +239,19 @@ int    swn_backward_bf16(const swn_net_desc* d, const float* packed_dev, const f
                          const float* fe_work_dev, const void* audio_dev, const float* fwd_work_dev,
                          const void* work_bf16_dev, const float* grad_out_dev, int batch, int n_frames,
                          float* work_dev, float* gpacked_dev, void* stream);
+/* Mixed-precision training at the GEMM-stack geometries (hid_chn % 64 == 0 outside the BL6 class): the bf16 forward that also
+ * keeps every layer's gate pre-activations (fp32, swn_forward_bf16_keep_floats() floats; 0 = variant not applicable), and the
+ * backward that reads them instead of recomputing each layer's dilated conv (1.7 of 13 ms per step at the run.sh geometry).
+ * swn_backward_keep takes swn_backward's arguments with a_keep_dev in place of hs_dev; fwd_work_dev is the fp32 expansion
+ * swn_bf16_work_to_f32 made of the same forward's work buffer. */
+size_t swn_forward_bf16_keep_floats(const swn_net_desc* d, int batch, int n_frames);
+int    swn_forward_bf16_keep(const swn_net_desc* d, const float* packed_dev, const void* wbf16_dev,
+                             const float* cond_dev, const void* audio_dev, int batch, int n_frames,
+                             void* work_dev, float* out_dev, float* a_keep_dev, void* stream);
+int    swn_backward_keep(const swn_net_desc* d, const float* packed_dev, const float* aux_dev, const float* cond_dev,
+                         const float* fe_work_dev, const void* audio_dev, const float* fwd_work_dev,
+                         const float* a_keep_dev, const float* grad_out_dev, int batch, int n_frames,
+                         float* work_dev, float* gpacked_dev, void* stream);
 /* ---- training-mode forward / backward WITH DROPOUT  (model.train(), forward(..., do=True) with do_prob > 0:
  *      cswnv_shift1.py:194-195,211-217,269-273 ; dswnv.py:253-254,264-270,278-282) --------------------------
  * The reference draws its Bernoulli masks inside nn.Dropout; here they are explicit inputs, like the decode

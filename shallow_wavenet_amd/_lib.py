@@ -83,6 +83,11 @@ SIGNATURES = {
     "swn_forward_drop": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "swn_unfold_grads_device": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "swn_forward_bf16_keep_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
+    "swn_forward_bf16_keep": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p, c_void_p]),
+    "swn_backward_keep": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                          c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "swn_backward_bf16_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_backward_bf16": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                           c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),

@@ -684,7 +684,8 @@ size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
 int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, bool hs_only, hipStream_t st);
 int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st);
 int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const void* audio,
-                      int batch, int n_frames, void* work, float* out, hipStream_t st);
+                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep = nullptr);
+size_t swn_bf16g_keep_floats(const SwnGeom& g, int batch, long Tp);
 
 extern "C" size_t swn_bf16_weight_bytes(const swn_net_desc* d) {
     SwnGeom g;
@@ -779,6 +780,28 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     const int hgrid = n_tiles < 512 ? n_tiles : 512;                            // two workgroups per CU
     hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 4 * 12 * 64 * 16, st, a, n_tiles);
     return swn_launch_status("swn_forward_bf16");
+}
+
+// Training variant at the GEMM-stack geometries: the same forward, and every layer's gate pre-activations (fp32, (B, 2H, Tp)
+// per layer) kept in a_keep_dev for swn_backward_keep, which then needs no recompute GEMM.  _keep_floats: 0 where the variant
+// does not apply (BL6 class: swn_backward_bf16 recomputes on chip).
+extern "C" size_t swn_forward_bf16_keep_floats(const swn_net_desc* d, int batch, int n_frames) {
+    SwnGeom g;
+    if (batch < 1 || n_frames < 1 || bf_geom(d, &g) == SWN_OK || swn_bf16g_geom(d, &g) < 0) return 0;
+    const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
+    return Tp < 1 ? 0 : swn_bf16g_keep_floats(g, batch, Tp);
+}
+
+extern "C" int swn_forward_bf16_keep(const swn_net_desc* d, const float* packed, const void* wbf, const float* cond,
+                                     const void* audio_, int batch, int n_frames, void* work, float* out, float* a_keep,
+                                     void* stream_) {
+    SwnGeom g;
+    if (bf_geom(d, &g) == SWN_OK) return SWN_E_UNSUPPORTED;
+    const int rc = swn_bf16g_geom(d, &g);
+    if (rc < 0) return rc;
+    if (!packed || !wbf || !cond || !audio_ || !work || !out || !a_keep || batch < 1 || batch > 65535 || n_frames < 1) return SWN_E_BADARG;
+    if ((long)n_frames * g.U - 2 * g.seg + 1 < 1) return SWN_E_BADARG;
+    return swn_bf16g_forward(g, packed, wbf, cond, audio_, batch, n_frames, work, out, (hipStream_t)stream_, a_keep);
 }
 
 // After swn_forward_bf16: expand what the forward kept (bf16, time-major) into the fp32 work layout of swn_forward, so

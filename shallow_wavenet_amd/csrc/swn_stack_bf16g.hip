@@ -46,6 +46,7 @@ struct GemmArgs {
     int H, l, seg, U, Tf, N, coff;
     const int* aidx; int Q;                        // softmax audio_in: class index of position t, or null
     int ntt, nmt;                                  // time tiles per utterance, row tiles (set by launch_gemm)
+    float* a_out;                                  // gate: where to keep the pre-activations (B, 2H, Tp) fp32 for the backward, or null
 };
 
 template <int EPI, int WNT>      // WNT: 16-column accumulator tiles per wave; the workgroup tile is 128 rows x 32*WNT positions
@@ -172,6 +173,11 @@ __global__ __launch_bounds__(256) void bf16g_gemm_kernel(const GemmArgs a) {
                 const uint2 hp2 = *reinterpret_cast<const uint2*>(a.hprev + ((size_t)b * a.Tp + t) * H + ch);
                 const float hp[4] = {bf2f((unsigned short)(hp2.x & 0xffff)), bf2f((unsigned short)(hp2.x >> 16)),
                                      bf2f((unsigned short)(hp2.y & 0xffff)), bf2f((unsigned short)(hp2.y >> 16))};
+                if (a.a_out) {     // training: the backward reads these instead of recomputing the dilated conv (64-byte runs along t)
+                    float* ao = a.a_out + ((size_t)b * H2 + ch) * a.Tp + t;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { ao[(size_t)r * a.Tp] = acc[2 * p][j][r]; ao[(size_t)(H + r) * a.Tp] = acc[2 * p + 1][j][r]; }
+                }
                 unsigned short hv[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -395,8 +401,12 @@ size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp) {
     return ((size_t)(g.L + 1) * g.H + g.S + g.O1) * batch * Tp * sizeof(unsigned short);
 }
 
+size_t swn_bf16g_keep_floats(const SwnGeom& g, int batch, long Tp) {
+    return (size_t)g.L * (((size_t)batch * 2 * g.H * Tp + 63) & ~(size_t)63);
+}
+
 int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, const float* cond, const void* audio,
-                      int batch, int n_frames, void* work, float* out, hipStream_t st) {
+                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep) {
     SwnLayout y; swn_make_layout(&g, &y);
     const GOff o = g_offsets(g);
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
@@ -427,8 +437,10 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
         a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K; a.src_bytes = lstride * 2;
         a.shift0 = (g.K - 1) * g.dil[l]; a.shift_step = g.dil[l];
         a.hprev = hs + (size_t)l * lstride; a.hnext = hs + (size_t)(l + 1) * lstride; a.l = l;
+        a.a_out = a_keep ? a_keep + (size_t)l * (((size_t)batch * 2 * g.H * Tp + 63) & ~(size_t)63) : nullptr;
         launch_gemm<EPI_GATE>(a, (int)tx, g.H / 64, batch, st);
     }
+    a.a_out = nullptr;
     // skip = relu(Wsk . [h_1 .. h_L] + b)
     a.A = wbf + o.wsk; a.M = g.S; a.Kd = g.L * g.H; a.src = hs + lstride; a.blk_stride = lstride; a.KB = g.H; a.nblk = g.L;
     a.src_bytes = (size_t)g.L * lstride * 2;

@@ -1200,7 +1200,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
                   const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
                   const float* drop_x, const float* const* drop_h,
                   const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_,
-                  const char* where, const void* hs_bf16 = nullptr) {
+                  const char* where, const void* hs_bf16 = nullptr, const float* a_keep = nullptr) {
     GateBwd ga;
     int rc = swn_make_geom(d, &ga.g);
     if (rc < 0) return rc;
@@ -1249,7 +1249,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     // dropout mode in the mixed-precision mode: swn_forward_drop of the same mode kept every layer's gate pre-activations
     // behind gx (the arithmetic mode must not change between a forward and its backward)
     const float* saved_a = (drop && g_train_bf16.load(std::memory_order_relaxed) == 1 && !hs_opt && swn_drop_bf16_forward(&g))
-                               ? gx + r64((size_t)B * L * H2 * Tp) : nullptr;
+                               ? gx + r64((size_t)B * L * H2 * Tp) : a_keep;   // a_keep: swn_forward_bf16_keep's buffer (same slots)
     float* dxm = dfe + r64(fe_tot * B * n_frames);
     float* hmask = dxm + r64((size_t)B * g.A0 * Tx);               // dropout mode only: masked input of a layer (B, H, Tp)
     if (hs_bf16) {                                     // compact layout: none of the fp32 sample-rate scratch exists
@@ -1436,6 +1436,16 @@ extern "C" int swn_backward_bf16(const swn_net_desc* d, const float* packed, con
     if (swn_backward_bf16_work_floats(d, batch, n_frames) == 0) return SWN_E_UNSUPPORTED;
     return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, nullptr, nullptr, nullptr, grad_out, batch, n_frames,
                          work, gpacked, stream_, "swn_backward_bf16", work_bf16);
+}
+
+// swn_backward after swn_forward_bf16_keep (GEMM-stack geometries, mixed-precision mode): the gate pre-activations come from
+// a_keep_dev, the recompute GEMM of every layer is skipped.  Everything else as swn_backward (same work size).
+extern "C" int swn_backward_keep(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
+                                 const float* fe_work, const void* audio, const float* fwd_work, const float* a_keep,
+                                 const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
+    if (!a_keep) return SWN_E_BADARG;
+    return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, nullptr, nullptr, nullptr, grad_out, batch, n_frames,
+                         work, gpacked, stream_, "swn_backward_keep", nullptr, a_keep);
 }
 
 extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames) {

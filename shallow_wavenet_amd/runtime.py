@@ -136,6 +136,7 @@ class HipNet:
         self.packed = packed.to(self.device, non_blocking=False).contiguous()
         self.packed_version = 0          # bumped by repack(): derived copies (bf16 weights) follow it
         self.fused_backward = True       # mixed-precision mode, BL6 class: swn_backward_bf16 (False: the generic chain)
+        self.keep_preactivations = True  # mixed-precision mode, GEMM-stack class: swn_forward_bf16_keep + swn_backward_keep
 
     def repack(self, tensors: Sequence[torch.Tensor]) -> None:
         """refresh the packed buffer IN PLACE from the live parameter tensors on the device (after an optimizer
@@ -233,7 +234,8 @@ class HipNet:
             res = self._bf16_train_forward(cond, audio, B, Tf)
             if res is not None:
                 out, wb, work = res
-                return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, work_bf16=wb, B=B, Tf=Tf)
+                return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, work_bf16=wb, a_keep=self._a_keep,
+                                 B=B, Tf=Tf)
         out, work, _ = _O.stack_forward(self.packed, cond, audio, self.dlist, False)
         return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
 
@@ -259,8 +261,16 @@ class HipNet:
             if getattr(self, "_wbf16_version", -1) != self.packed_version:
                 _lib.check(L.swn_pack_bf16(d, _ptr(self.packed), _ptr(self._wbf16), st), "pack_bf16")
                 self._wbf16_version = self.packed_version
-            _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
-                                          _ptr(wb), _ptr(out), st), "forward_bf16")
+            nkeep = L.swn_forward_bf16_keep_floats(d, B, Tf) if self.keep_preactivations else 0
+            if nkeep:
+                # GEMM-stack geometries: the forward also keeps the gate pre-activations, the backward skips its recompute GEMMs
+                self._a_keep = torch.empty(nkeep, dtype=torch.float32, device=self.device)
+                _lib.check(L.swn_forward_bf16_keep(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
+                                                   _ptr(wb), _ptr(out), _ptr(self._a_keep), st), "forward_bf16_keep")
+            else:
+                self._a_keep = None
+                _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
+                                              _ptr(wb), _ptr(out), st), "forward_bf16")
         fused = self.fused_backward and _ops.backward_bf16_supported(self.dlist, B, Tf)
         return out, wb, (None if fused else self._expand_bf16_work(wb, B, Tf))
 
@@ -330,6 +340,14 @@ class HipNet:
                                                  wb, grad_raw, self.dlist)
         if saved["work"] is None:                      # the forward counted on the fused backward
             saved["work"] = self._expand_bf16_work(wb, B, Tf)
+        if saved.get("a_keep") is not None and L.swn_train_get_precision() == 1:
+            work = torch.empty(L.swn_backward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+            gp = torch.empty_like(self.packed)
+            with _ops._on(self.device):
+                _lib.check(L.swn_backward_keep(d, _ptr(self.packed), _ptr(saved["aux"]), _ptr(saved["cond"]), _ptr(saved["fe_work"]),
+                                               _ptr(saved["audio"]), _ptr(saved["work"]), _ptr(saved["a_keep"]), _ptr(grad_raw), B, Tf,
+                                               _ptr(work), _ptr(gp), _stream_ptr(self.device)), "backward_keep")
+            return gp
         return _ops.stack_backward_impl(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
                                         saved["work"], grad_raw, self.dlist)
 

@@ -240,3 +240,34 @@ def test_softmax_run_sh_geometry_bf16_mode(gpu_ok):
     big = max(np.linalg.norm(v.ravel()) for v in out["fp32"].values())
     # nine layers deep, both passes rounded, random labels: the frame-rate front end (norm 7e-3 of 0.02) sits at 5-6 %
     _close("ref6_softmax", out["bf16"], out["fp32"], tol=1e-1, floor=1e-3 * big)
+
+
+def test_kept_preactivations_match_the_recompute(gpu_ok):
+    """GEMM-stack class, mixed-precision mode: swn_forward_bf16_keep + swn_backward_keep (no recompute GEMM) against
+    swn_forward_bf16 + swn_backward (recompute from the expanded hidden states) - the same bf16 operands either way, so the
+    packed gradients agree to summation order."""
+    from shallow_wavenet_amd.runtime import HipNet
+    for cfg in (C.ref6_laplace(1, 4), C.ref6_softmax()):
+        net = HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True), "cuda:0")
+        B, Tf = 2, 9
+        soft = cfg.kind == "softmax"
+        aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+        T = Tf * cfg.U
+        g = torch.Generator().manual_seed(2)
+        if soft:
+            audio = torch.randint(0, cfg.n_quantize, (B, T - 1), generator=g).cuda()
+            Tp = T - 1
+        else:
+            audio = (torch.rand(B, 1, T - cfg.seg, generator=g) * 1.8 - 0.9).cuda()
+            Tp = T - 2 * cfg.seg + 1
+        grad_raw = (torch.randn(B, cfg.n_out, Tp, generator=g) / Tp).cuda()
+        got = {}
+        with train_precision("bf16"):
+            for keep in (True, False):
+                net.keep_preactivations = keep
+                raw, saved = net.forward_train(aux, audio)
+                assert (saved.get("a_keep") is not None) == keep
+                got[keep] = (raw.clone(), net.backward(saved, grad_raw).clone())
+        assert torch.equal(got[True][0], got[False][0])
+        a, b = got[True][1].double(), got[False][1].double()
+        assert float((a - b).norm()) <= 2e-3 * float(b.norm()), (cfg.kind, float((a - b).norm()), float(b.norm()))
