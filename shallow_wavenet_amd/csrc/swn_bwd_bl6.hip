@@ -66,9 +66,6 @@ __device__ __forceinline__ float4 ld_f4(__amdgpu_buffer_rsrc_t r, unsigned off) 
 __device__ __forceinline__ float ld_f1(__amdgpu_buffer_rsrc_t r, unsigned off) {
     return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0));
 }
-__device__ __forceinline__ void st_f1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, off, 0, 0);
-}
 
 // sum over the 16 lanes of a DPP row (lanes 16g .. 16g+15), result in every lane of the row
 template <int CTRL>
