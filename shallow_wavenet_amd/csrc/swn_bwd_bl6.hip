@@ -1,13 +1,15 @@
-// Fused per-layer backward of the BL6-class stack (H=64, K=2, seg=1, Laplace) in the mixed-precision training mode:
-// the gradient side of CSWNV.forward's gated layers (cswnv_shift1.py:269-278, loss.backward() of
-// train_cswnv_laplace-stftcmplx_shift1.py:868-874), reading the bf16 time-major hidden states the bf16 forward
-// (csrc/swn_stack_bf16.hip) kept.
+// Fused backward of the BL6-class stack (H=64, K=2, seg=1, Laplace) in the mixed-precision training mode: the gradient
+// side of CSWNV.forward (cswnv_shift1.py:191-278; loss.backward() of train_cswnv_laplace-stftcmplx_shift1.py:868-874) -
+// head, gated layers, input layer - reading the bf16 time-major hidden states the bf16 forward (csrc/swn_stack_bf16.hip)
+// kept.  Entry: swn_bl6_bwd_stack (called by swn_backward_bf16, csrc/swn_train.hip).
 //
 // The generic chain of csrc/swn_train.hip runs five launches per layer (recompute GEMM, gate, weight gradient, data
 // gradient, conditioning) that hand 2H x T fp32 tensors to each other through HBM: ~750 MB per layer at BASELINE cfg4,
-// which is what bounds it.  Here one launch per layer does everything that is local in time:
+// which is what bounds it - plus an fp32 expansion of the bf16 activations and six launches for the head.  Here:
 //
-//   bl6_layer_bwd_kernel   per 16-position chunk (one wave, no barriers in the loop)
+//   bl6_head_bwd_kernel    one launch: recompute relu(skip), relu(out_1); d out_1, d skip; g out_2 in registers;
+//                          relu(skip), d out_1, d skip leave as bf16 [t][128] rows
+//   bl6_layer_bwd_kernel   one launch per gated layer, per 16-position chunk (one wave, no barriers in the loop):
 //        dh   = E_{l+1}(t) + [Wd_{l+1}^T | Wsk_l^T] (*) [da_{l+1} ; dskip]
 //                                                          the data gradient of the layer ABOVE from the da it stored (so
 //                                                          no halo is recomputed and nothing is atomically scattered),
@@ -17,16 +19,18 @@
 //        E_l  = dh * z                                     highway carry, fp32 TIME-MAJOR [t][64] (ping-pong buffers)
 //        da_l -> bf16 time-major [t][128]                  operand of the next launch's data gradient and of the
 //                                                          weight-gradient kernel
-//        dcond[b][f][l] = sum_{t in f} w_up . dgx          work unit = one conditioning frame: plain stores
+//        dcond[b][f][l] = sum_{t in f} w_up . dgx          work unit = one conditioning frame (or one channel half of it):
+//                                                          plain stores
 //        g b_inx, g w_up                                   lane / LDS accumulators, a few atomics per workgroup
-//   bl6_wgrad_kernel       g Wd_l += da_l x [h_l(t-d) ; h_l(t)]^T and g bd_l for all layers in one launch: time is the
-//                          reduction axis, so both operands are staged time-major in LDS exactly as they lie in HBM
-//                          and read back transposed by ds_read_b64_tr_b16.
+//      and a last launch (MODE 2) that assembles d h_0 and does the input layer from its accumulators
+//   bl6_wgrad_kernel       one launch, ten 128 x 128 jobs (six dil_h, three column blocks of out_skip, out_1) + their
+//                          biases: time is the reduction axis, so both operands are staged time-major in LDS exactly as
+//                          they lie in HBM and read back transposed by ds_read_b64_tr_b16.
 // Every stream is time-major, i.e. whole 128/256-byte rows per position (a first version kept the carries in the generic
 // chain's channel-major fp32 layout: 64-byte pieces of 64 different rows per chunk, 2.5 TB/s at best).
-// Algorithmic HBM bytes per position and layer: h 128 + E_{l+1} 256 + da_{l+1} 256 + dskip 256 + E_l 256 + da_l 256
-// = 1.4 KB, plus 384 for the weight gradient, against ~5.7 KB of the generic chain (which also needs the skip path's
-// data gradient as a separate 384 x 128 GEMM and a memset of the carries).
+// Algorithmic HBM bytes per position: layer launch h 128 + E_{l+1} 256 + da_{l+1} 256 + dskip 256 + E_l 256 + da_l 256
+// = 1.4 KB (the chain: ~5.7 KB, plus the skip path's data gradient as a separate 384 x 128 GEMM and a memset of the
+// carries); head 1.8 KB; weight-gradient jobs 512 B each.
 #include <hip/hip_runtime.h>
 #include <hip/hip_bf16.h>
 #include "swn_geom.hpp"
