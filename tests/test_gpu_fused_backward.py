@@ -67,9 +67,9 @@ def test_fused_layers_match_the_chain(gpu_ok, B, Tf, lpc):
 
 
 def test_fused_backward_other_upsampling(gpu_ok):
-    """U = 80 (5 chunks per frame, none ragged) and U = 37 (3 chunks, ragged)."""
+    """U = 80 (5 chunks per frame, none ragged), U = 37 (3 chunks, ragged), and the two ends of the covered range: 16 and 112."""
     import dataclasses
-    for U in (80, 37):
+    for U in (80, 37, 16, 112):
         cfg = dataclasses.replace(C.bl6_laplace(1, 0), upsampling_factor=U)
         net, g1, g0 = _run(cfg, 2, 7)
         s1, s0 = _sections(cfg, g1), _sections(cfg, g0)
