@@ -132,6 +132,13 @@ __global__ void __launch_bounds__(256) pack_params_kernel(PackArgs a, float* __r
                 const int A = g.A0 * seg + (g.audio_in ? Q : 0), n = g.A0 * seg;
                 const float* row = a.t[a.i_inx + 2 * l] + (size_t)o * A;
                 int k = 0;
+                for (; k + 64 <= n; k += 64) {               // (2 430 terms per row at run.sh's seg = 5: 64 loads per round trip)
+                    float v[64];
+#pragma unroll
+                    for (int u = 0; u < 64; ++u) v[u] = row[k + u];
+#pragma unroll
+                    for (int u = 0; u < 64; ++u) ws += v[u];
+                }
                 for (; k + 16 <= n; k += 16) {
                     float v[16];
 #pragma unroll
@@ -233,7 +240,9 @@ extern "C" int swn_pack_params_device(const swn_net_desc* d, const float* const*
     hipStream_t st = (hipStream_t)stream;
     // padding lanes (Hp/Sp/A0p tails, section gaps) must read as zero, like the host packer's memset
     if (hipMemsetAsync(packed_dev, 0, a.y.total * sizeof(float), st) != hipSuccess) return swn_launch_status("pack_params_device memset");
-    dim3 grid(256, SEC_COUNT);
+    // enough workgroups for the largest section of the largest nets (run.sh's seg = 5 in_x: 5.6 M elements; with 256 workgroups
+    // every thread walked 85 elements through a chain of integer divisions: 161 us)
+    dim3 grid(a.y.total > (4u << 20) ? 1024 : 256, SEC_COUNT);
     hipLaunchKernelGGL(pack_params_kernel, grid, dim3(256), 0, st, a, packed_dev);
     return swn_launch_status("pack_params_device");
 }

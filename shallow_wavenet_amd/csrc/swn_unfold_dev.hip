@@ -118,15 +118,21 @@ __global__ void __launch_bounds__(256) unfold_grads_kernel(const UnfoldArgs a, c
                     const int k = (int)(e % K), i = (int)((e / K) % H), o = (int)(e / (unsigned)(K * H));
                     dwc[e] = gcv[k * H + o] * ww[i] + gcc[k * H + o] * wb[i];
                 }
-            for (unsigned i = tid; i < (size_t)H; i += nth) {
+            // one wave per lifted channel i, its lanes over the H*K taps (a thread per i walked 1 344 strided loads one after
+            // the other at the run.sh geometry: ~200 us, the whole kernel's time)
+            for (unsigned i = tid >> 6; i < (unsigned)H; i += nth >> 6) {
                 double sw = 0.0, sb = 0.0;
-                for (int o = 0; o < H; ++o)
-                    for (int k = 0; k < K; ++k) {
-                        const double w = wc[((size_t)o * H + i) * K + k];
-                        sw += w * gcv[k * H + o]; sb += w * gcc[k * H + o];
-                    }
-                if (a.o[a.i_wav]) a.o[a.i_wav][i] = (float)sw;
-                if (a.o[a.i_wav + 1]) a.o[a.i_wav + 1][i] = (float)sb;
+                for (int e = (int)(threadIdx.x & 63); e < H * K; e += 64) {
+                    const int o = e / K, k = e - o * K;
+                    const double w = wc[((size_t)o * H + i) * K + k];
+                    sw += w * gcv[k * H + o]; sb += w * gcc[k * H + o];
+                }
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) { sw += __shfl_xor(sw, sft); sb += __shfl_xor(sb, sft); }
+                if ((threadIdx.x & 63) == 0) {
+                    if (a.o[a.i_wav]) a.o[a.i_wav][i] = (float)sw;
+                    if (a.o[a.i_wav + 1]) a.o[a.i_wav + 1][i] = (float)sb;
+                }
             }
         } else {
             const float* gct = gp + y.ct;                                 // [K][Q][H]
@@ -221,6 +227,6 @@ extern "C" int swn_unfold_grads_device(const swn_net_desc* d, const float* gpack
     if (a.o[a.i_up + 1] && hipMemsetAsync(a.o[a.i_up + 1], 0, sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     if (a.g.kind == SWN_KIND_SOFTMAX && a.g.wav && a.o[a.i_wav + 1] &&
         hipMemsetAsync(a.o[a.i_wav + 1], 0, (size_t)a.g.H * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
-    hipLaunchKernelGGL(unfold_grads_kernel, dim3(128, U_COUNT), dim3(256), 0, st, a, gpacked_dev);
+    hipLaunchKernelGGL(unfold_grads_kernel, dim3(a.y.total > (4u << 20) ? 768 : 128, U_COUNT), dim3(256), 0, st, a, gpacked_dev);
     return swn_launch_status("swn_unfold_grads_device");
 }
