@@ -189,14 +189,15 @@ def _stft(x: torch.Tensor, n_fft: int, window: torch.Tensor) -> torch.Tensor:
 
 def batch_loss(model, criterion_laplace, criterion_lsd, batch_h, batch_x, target, x_prob, feat_len, h_ss,
                fft_facts: Sequence[int], hann_win: Sequence[torch.Tensor], do: bool = True,
-               eps_generator: Optional[torch.Generator] = None):
+               eps_generator: Optional[torch.Generator] = None, eps_on_device: bool = False):
     """forward + loss of one chunk (train_cswnv...py:744-868): returns
     (batch_loss, batch_loss_laplace, batch_loss_lsd or None, batch_loss_err).
 
     mean of the LP part: a = flip(a); for j < seg: mu_j += sum_k a_k * x[t+j-lpc+k] by `unfold` on the LP context;
     loss = mean_j NLL_j + mean_j mean_fft L1(STFT(sample_j), STFT(target_j)) with
-    sample = mu - b_noclip * sign(eps) * log1p(-2|eps|), eps ~ U(-0.4999, 0.5) drawn on the HOST generator here
-    (the reference draws it on the device)."""
+    sample = mu - b_noclip * sign(eps) * log1p(-2|eps|), eps ~ U(-0.4999, 0.5): drawn on the HOST generator by default (what
+    the g6_trainstep fixtures replay), with eps_on_device=True on the model's device like the reference (the driver does
+    that whenever its dropout masks are device-drawn: a host draw is a pageable host->device copy per segment)."""
     seg, lpc, rf = model.seg, model.lpc, model.receptive_field
     if lpc > 0:
         mus, bs_noclip, bs, log_bs, ass = model(batch_h, batch_x, do=do, clip=True)
@@ -216,6 +217,8 @@ def batch_loss(model, criterion_laplace, criterion_lsd, batch_h, batch_x, target
         mus, bs_noclip, bs, log_bs = mus[0], bs_noclip[0], bs[0], log_bs[0]
 
     def draw(shape):
+        if eps_on_device:
+            return torch.empty(shape, device=mus.device).uniform_(-0.4999, 0.5)
         return torch.empty(shape).uniform_(-0.4999, 0.5, generator=eps_generator).to(mus.device)
 
     # The spectral terms (train_cswnv...py:786-868).  The reference runs, per segment j and per FFT size, two `torch.stft`s
@@ -366,8 +369,9 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--synthetic", default=0, type=int, help="train on N generated utterances (no files needed)")
     p.add_argument("--max_iters", default=0, type=int, help="stop after this many chunks (0 = run all epochs)")
     p.add_argument("--dropout_source", default="device", choices=["device", "host"],
-                   help="where the nn.Dropout masks are drawn: the model's device (like the reference on a GPU) or the torch "
-                        "CPU generator in the reference's order (reproduces a CPU run of the reference; ~1 s per chunk)")
+                   help="where the nn.Dropout masks (and the loss's reparameterisation noise) are drawn: the model's device (like "
+                        "the reference on a GPU) or the torch CPU generator in the reference's order (reproduces a CPU run of "
+                        "the reference; ~0.1 s per chunk, ~1 s at cfg4's batch)")
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                    help="arithmetic of the training step's contractions (not a reference flag): fp32 = parity mode, "
                         "bf16 = bf16 operands with fp32 accumulation (swn_train_set_precision)")
@@ -412,6 +416,7 @@ def main(argv=None) -> int:
                   do_prob=args.do_prob, seg=args.seg, lpc=args.lpc, aux_conv2d_flag=args.aux_conv2d_flag,
                   wav_conv_flag=args.wav_conv_flag, upsampling_factor=args.upsampling_factor)
     model.dropout_source = args.dropout_source
+    dev_rng = args.dropout_source == "device"          # the loss's reparameterisation noise follows the same choice
     logging.info(model)
     criterion_lsd, criterion_laplace = LSDloss().cuda(), LaplaceLoss().cuda()
     dev = torch.device("cuda")
@@ -486,7 +491,7 @@ def main(argv=None) -> int:
                 with torch.no_grad():
                     bh, bx, trg, xp, flen = slice_chunk(model, x, h, h_bs, x_bs, h_ss, x_ss)
                     _, l_lap, l_lsd, l_err = batch_loss(model, criterion_laplace, criterion_lsd, bh, bx, trg, xp, flen,
-                                                        h_ss, fft_facts, hann_win, do=False)
+                                                        h_ss, fft_facts, hann_win, do=False, eps_on_device=dev_rng)
                 ev_lap.append(l_lap.item()); ev_err.append(l_err.item())
                 if l_lsd is not None:
                     ev_lsd.append(l_lsd.item())
@@ -521,7 +526,7 @@ def main(argv=None) -> int:
         tf, ts = h.shape[0], x.shape[0]
         bh, bx, trg, xp, flen = slice_chunk(model, x, h, h_bs, x_bs, h_ss, x_ss)
         loss, l_lap, l_lsd, l_err = batch_loss(model, criterion_laplace, criterion_lsd, bh, bx, trg, xp, flen, h_ss,
-                                               fft_facts, hann_win, do=True)
+                                               fft_facts, hann_win, do=True, eps_on_device=dev_rng)
         optimizer.zero_grad()
         loss.backward()
         optimizer.step()
