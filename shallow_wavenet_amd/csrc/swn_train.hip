@@ -20,6 +20,8 @@ namespace {
 
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + expf(-x)); }
 
+constexpr int SWN_WUP_COPIES = 16;      // see wup_fold_kernel
+
 struct TimeGemm {
     const float* A; long a_sm, a_stap, a_sc;        // A(m, tap, c)
     const float* X; long x_sb, x_sc, x_st;          // X[b][c][t]
@@ -731,10 +733,24 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z * im;   // highway path (through the input's dropout mask)
 }
 
+// cond_bwd_kernel adds its upsampler-tap sums into one of SWN_WUP_COPIES zeroed copies (chosen by workgroup index) instead of
+// straight into g w_up: ~800 workgroups per launch finish together, and 800 same-address float atomics per tap (~25 ns each
+// at the L2) were a 20 us serial tail of a 66 us kernel.  wup_fold_kernel adds the copies into the packed gradient once, after
+// the last layer.
+__global__ __launch_bounds__(256) void wup_fold_kernel(const float* __restrict__ part, float* __restrict__ gwup, const int U) {
+    const int jj = threadIdx.x;
+    if (jj >= U) return;
+    float v = 0.f;
+#pragma unroll
+    for (int c = 0; c < SWN_WUP_COPIES; ++c) v += part[c * 256 + jj];
+    atomicAdd(gwup + jj, v);
+}
+
 // ---- hoisted conditioning backward, two orientations of the same (frame x tap) product:
 //      threads 0..63    thread = in_x row o2:  dcond[b][f][(l*seg+s)*2H+o2] = sum_jj w_up[jj] * dgx[o2][t] ; gbx
 //      threads 64..255  thread = upsampler tap jj:  gwup[jj] += sum_{s,o2} dgx[o2][t] * cond[b][f][(l*seg+s)*2H+o2]
 //      with t = f*U + jj - s - coff  (the positions whose conditioning comes from frame f, tap jj)
+template <int NCH>
 __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* __restrict__ dcond, float* __restrict__ gbx,
                                                        float* __restrict__ gwup, const int FR) {
     // workgroup = (64 in_x rows, FR consecutive frames, utterance b).  Per frame the U + seg - 1 positions it touches are
@@ -746,8 +762,8 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     extern __shared__ float tile_mem[];
     const int pitch = (a.g.U + a.g.seg - 1) | 1;
     auto tile = [&](int r, int c) -> float& { return tile_mem[r * pitch + c]; };
-    __shared__ float wus[256];
-    __shared__ float cs[10][64];                 // seg <= 10 (swn_make_geom)
+    __shared__ __attribute__((aligned(16))) float wus[256];
+    __shared__ __attribute__((aligned(16))) float cs[10][64];                 // seg <= 10 (swn_make_geom)
     const SwnGeom& g = a.g;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.z;
     const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
@@ -757,26 +773,47 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     const int o2 = blockIdx.x * 64 + tid;
     float bsum = 0.f, wacc[2] = {0.f, 0.f};      // tid < 64: row sum ; tid >= 64: taps tid - 64 and tid + 128
     const int f1 = (blockIdx.y + 1) * FR < a.Tf ? (blockIdx.y + 1) * FR : a.Tf;
-    for (int f = blockIdx.y * FR; f < f1; ++f) {
+    // One frame ahead in registers: the loads of frame f + 1 (its dgx tile: NCH chunks of 64 columns x 16 rows per wave, and its
+    // in_x products) are issued right after the barrier that publishes frame f, so their round trip runs under frame f's
+    // multiply-adds instead of in front of frame f + 1's (a workgroup used to spend ~9 us per frame, three dependent round trips).
+    const __amdgpu_buffer_rsrc_t rC = rsrc_of(a.cond + (size_t)b * a.Tf * g.N);
+    float v[NCH][16], cpre[3];
+    auto fetch = [&](const int f) {
         const int tbeg = f * U - (seg - 1) - a.coff;                              // tile column c <-> position tbeg + c
-        for (int e = tid; e < seg * 64; e += 256) {                               // this frame's in_x products for the 64 rows
-            const int sx = e >> 6, r2 = blockIdx.x * 64 + (e & 63);
-            cs[sx][e & 63] = r2 < H2 ? a.cond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + sx) * H2 + r2] : 0.f;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                                             // seg <= 10: at most 640 products
+            const int e = tid + 256 * k, sx = e >> 6, r2 = blockIdx.x * 64 + (e & 63);
+            cpre[k] = bld1(rC, (e < seg * 64 && r2 < H2) ? (unsigned)(((size_t)f * g.N + (size_t)(l * seg + sx) * H2 + r2) * 4) : SWN_OOB);
         }
-        // 16 rows per wave, all 16 loads of a 64-column chunk in flight (branch-free: out-of-range offset = zero)
-        for (int c = lane; c < ncol; c += 64) {
-            const int t = tbeg + c;
-            const bool tok = t >= 0 && t < a.Tp;
-            float v[16];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = lane + 64 * k, t = tbeg + c;
+            const bool tok = c < ncol && t >= 0 && t < a.Tp;
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int r2 = blockIdx.x * 64 + w + 4 * i;
-                v[i] = bld1(rD, (tok && r2 < H2) ? (unsigned)(((size_t)r2 * a.Tp + t) * 4) : SWN_OOB);
+                v[k][i] = bld1(rD, (tok && r2 < H2) ? ((unsigned)r2 * (unsigned)a.Tp + (unsigned)t) * 4u : SWN_OOB);
             }
+        }
+    };
+    fetch(blockIdx.y * FR);
+    for (int f = blockIdx.y * FR; f < f1; ++f) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) tile(w + 4 * i, c) = v[i];
+        for (int k = 0; k < 3; ++k) { const int e = tid + 256 * k; if (e < seg * 64) cs[e >> 6][e & 63] = cpre[k]; }
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = lane + 64 * k;
+            if (c < ncol) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) tile(w + 4 * i, c) = v[k][i];
+            }
         }
         __syncthreads();
+        if (f + 1 < f1) fetch(f + 1);
+        __builtin_amdgcn_sched_barrier(0);                                        // keep the requests above the LDS loops
+        // Both orientations read LDS in batches of eight independent loads: written as plain accumulation loops the compiler
+        // kept one read in flight (read, wait, fma), and the 110 dependent LDS round trips of wave 0 - ~6 us per frame - were
+        // the kernel.
         if (tid >= 64) {
             // the other orientation of the same tile (was a second pass over dgx, wup_bwd_kernel): thread = upsampler tap jj,
             // gwup[jj] += sum_{s, rows} dgx[row][t(jj, s)] * cond[f][(l*seg+s)*2H + row]   (columns: conflict-free, pitch odd)
@@ -786,29 +823,47 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
                 if (jj < U) {
                     float acc = 0.f;
                     for (int sx = 0; sx < seg; ++sx) {
-                        const int c = jj + (seg - 1) - sx;
-#pragma unroll 8
-                        for (int r = 0; r < 64; ++r) acc = fmaf(tile(r, c), cs[sx][r], acc);
+                        const float* col = tile_mem + jj + (seg - 1) - sx;
+                        for (int r = 0; r < 64; r += 8) {
+                            float d[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) d[e] = col[(r + e) * pitch];
+                            const swn_fl4 c0 = *reinterpret_cast<const swn_fl4*>(&cs[sx][r]);
+                            const swn_fl4 c1 = *reinterpret_cast<const swn_fl4*>(&cs[sx][r + 4]);
+                            acc = fmaf(d[0], c0.x, acc); acc = fmaf(d[1], c0.y, acc); acc = fmaf(d[2], c0.z, acc); acc = fmaf(d[3], c0.w, acc);
+                            acc = fmaf(d[4], c1.x, acc); acc = fmaf(d[5], c1.y, acc); acc = fmaf(d[6], c1.z, acc); acc = fmaf(d[7], c1.w, acc);
+                        }
                     }
                     wacc[q] += acc;
                 }
             }
         } else if (o2 < H2) {
             for (int s = 0; s < seg; ++s) {
-                float dsum = 0.f;
-                for (int jj = 0; jj < U; ++jj) {
-                    const float d = tile(tid, jj + (seg - 1) - s);       // t = f*U + jj - s - coff
-                    dsum = fmaf(wus[jj], d, dsum);
-                    if (s == 0) bsum += d;                               // every position belongs to exactly one (f, jj) at s = 0
+                const float* row = tile_mem + tid * pitch + (seg - 1) - s;       // t = f*U + jj - s - coff
+                float dsum = 0.f, psum = 0.f;
+                int jj = 0;
+                for (; jj + 8 <= U; jj += 8) {
+                    float d[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[e] = row[jj + e];
+                    const swn_fl4 w0 = *reinterpret_cast<const swn_fl4*>(&wus[jj]);
+                    const swn_fl4 w1 = *reinterpret_cast<const swn_fl4*>(&wus[jj + 4]);
+                    dsum = fmaf(w0.x, d[0], dsum); dsum = fmaf(w0.y, d[1], dsum); dsum = fmaf(w0.z, d[2], dsum); dsum = fmaf(w0.w, d[3], dsum);
+                    dsum = fmaf(w1.x, d[4], dsum); dsum = fmaf(w1.y, d[5], dsum); dsum = fmaf(w1.z, d[6], dsum); dsum = fmaf(w1.w, d[7], dsum);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) psum += d[e];
                 }
+                for (; jj < U; ++jj) { const float d = row[jj]; dsum = fmaf(wus[jj], d, dsum); psum += d; }
+                if (s == 0) bsum += psum;                                        // every position belongs to exactly one (f, jj) at s = 0
                 dcond[((size_t)b * a.Tf + f) * g.N + (size_t)(l * seg + s) * H2 + o2] = dsum;
             }
         }
         __syncthreads();                                                   // the tile is free for the next frame
     }
     if (tid >= 64) {
+        float* part = gwup + 256 * ((blockIdx.x + 3 * blockIdx.y + 5 * blockIdx.z) & (SWN_WUP_COPIES - 1));   // gwup: the zeroed copies
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { const int jj = tid - 64 + 192 * q; if (jj < U) atomicAdd(gwup + jj, wacc[q]); }
+        for (int q = 0; q < 2; ++q) { const int jj = tid - 64 + 192 * q; if (jj < U) atomicAdd(part + jj, wacc[q]); }
     } else if (o2 < H2) {
         atomicAdd(gbx + (size_t)l * H2 + o2, bsum);
     }
@@ -1000,7 +1055,8 @@ extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int
     if (Tp < 1) return 0;
     size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
     return r64((size_t)batch * g.O1 * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * (g.L + 1) * g.H * Tp) +
-           2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames);
+           2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) +
+           (size_t)SWN_WUP_COPIES * 256;       // partial upsampler-tap gradients of cond_bwd_kernel
 }
 
 namespace {
@@ -1258,6 +1314,9 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         dxm = dfe + r64(fe_tot * B * n_frames);
     }
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
+    // teacher-forced chain without dropout: the partial g w_up copies of cond_bwd_kernel sit where the dropout mode keeps dxm
+    float* wup_part = (!hs_bf16 && !drop) ? dxm : nullptr;
+    if (wup_part && hipMemsetAsync(wup_part, 0, (size_t)SWN_WUP_COPIES * 256 * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
     if (!hs_bf16 && hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     const long hsb = (long)(L + 1) * H * Tp;
@@ -1340,9 +1399,11 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             // frames per workgroup: as many as still leave ~768 workgroups
             const int rb = (H2 + 63) / 64;
             int FR = (int)(((long)rb * n_frames * B) / 768); FR = FR < 1 ? 1 : (FR > 16 ? 16 : FR);
-            hipLaunchKernelGGL(cond_bwd_kernel, dim3(rb, (n_frames + FR - 1) / FR, B), dim3(256),
-                               (size_t)64 * ((g.U + g.seg - 1) | 1) * sizeof(float), st, ga, dcond, gpacked + y.bx,
-                               gpacked + y.wup, FR);
+            const dim3 cgrid(rb, (n_frames + FR - 1) / FR, B);
+            const size_t clds = (size_t)64 * ((g.U + g.seg - 1) | 1) * sizeof(float);
+            const int cch = (g.U + g.seg - 1 + 63) / 64;                              // 64-column chunks of a frame's tile (U <= 256: at most 5)
+            if (cch <= 2) hipLaunchKernelGGL(cond_bwd_kernel<2>, cgrid, dim3(256), clds, st, ga, dcond, gpacked + y.bx, wup_part, FR);
+            else hipLaunchKernelGGL(cond_bwd_kernel<5>, cgrid, dim3(256), clds, st, ga, dcond, gpacked + y.bx, wup_part, FR);
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
             {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
@@ -1360,6 +1421,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             }
         }
     }
+    if (wup_part) hipLaunchKernelGGL(wup_fold_kernel, dim3(1), dim3(256), 0, st, wup_part, gpacked + y.wup, g.U);
     // ---- input layer (the fused layer path has done it from its accumulators)
     if (hs_bf16) {}
     else if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(input_bwd_kernel<SWN_KIND_LAPLACE>, dim3(H, B), dim3(256), 0, st, ga, gpacked);
