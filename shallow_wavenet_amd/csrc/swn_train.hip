@@ -733,6 +733,12 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z * im;   // highway path (through the input's dropout mask)
 }
 
+// zeroes `n` floats at the start of each of gridDim.y rows `stride` floats apart
+__global__ __launch_bounds__(256) void zero_rows_kernel(float* __restrict__ p, const size_t stride, const size_t n) {
+    float* row = p + (size_t)blockIdx.y * stride;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) row[i] = 0.f;
+}
+
 // cond_bwd_kernel adds its upsampler-tap sums into one of SWN_WUP_COPIES zeroed copies (chosen by workgroup index) instead of
 // straight into g w_up: ~800 workgroups per launch finish together, and 800 same-address float atomics per tap (~25 ns each
 // at the L2) were a 20 us serial tail of a 66 us kernel.  wup_fold_kernel adds the copies into the packed gradient once, after
@@ -884,22 +890,37 @@ __global__ __launch_bounds__(256) void input_bwd_kernel(const GateBwd a, float* 
 #pragma unroll
     for (int k = 0; k < 8; ++k) { kv[k] = (KIND == SWN_KIND_LAPLACE && k < K) ? P[a.y.cv + (size_t)k * H + o] : 0.f;
                                   kc[k] = (KIND == SWN_KIND_LAPLACE && k < K) ? P[a.y.cc + (size_t)k * H + o] : 0.f; }
-    for (int t = threadIdx.x; t < a.Tp; t += 256) {
+    if (KIND == SWN_KIND_LAPLACE) {
+        // four positions per thread and trip, all their loads requested before the first is used (one position per trip was a
+        // chain of 65 dependent HBM round trips per thread: 84 us for 101 MB); out-of-range = the zero of a buffer load
+        const __amdgpu_buffer_rsrc_t rA = rsrc_of(reinterpret_cast<const float*>(a.audio) + (size_t)b * (a.Tp + g.seg - 1));
+        const __amdgpu_buffer_rsrc_t rD = rsrc_of(dh0);
+        for (int t0 = threadIdx.x; t0 < a.Tp; t0 += 1024) {
+            float dh[4], x[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int t = t0 + 256 * u, ai = t + g.seg - 1;
+                const bool ok = t < a.Tp;
+                dh[u] = bld1(rD, ok ? (unsigned)t * 4u : SWN_OOB);
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); x[u][k] = bld1(rA, (ok && k < K && r >= 0) ? (unsigned)r * 4u : SWN_OOB); }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int ai = t0 + 256 * u + g.seg - 1;
+                float pre = kb;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); if (k < K && r >= 0) pre += fmaf(kv[k], x[u][k], kc[k]); }
+                const float d = dh[u] / ((1.f + fabsf(pre)) * (1.f + fabsf(pre)));      // dh = 0 past the end
+                scb += d;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); if (k < K && r >= 0) { sv[k] = fmaf(d, x[u][k], sv[k]); sc[k] += d; } }
+            }
+        }
+    }
+    for (int t = threadIdx.x; KIND != SWN_KIND_LAPLACE && t < a.Tp; t += 256) {
         float pre = kb;
-        if (KIND == SWN_KIND_LAPLACE) {
-            const float* au = reinterpret_cast<const float*>(a.audio) + (size_t)b * (a.Tp + g.seg - 1);
-            const int ai = t + g.seg - 1;
-            float x[8];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); x[k] = (k < K && r >= 0) ? au[r] : 0.f; }
-            const float dh = dh0[t];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); if (k < K && r >= 0) pre += fmaf(kv[k], x[k], kc[k]); }
-            const float d = dh / ((1.f + fabsf(pre)) * (1.f + fabsf(pre)));
-            scb += d;
-#pragma unroll
-            for (int k = 0; k < 8; ++k) { const int r = ai - (K - 1 - k); if (k < K && r >= 0) { sv[k] = fmaf(d, x[k], sv[k]); sc[k] += d; } }
-        } else {
+        {
             const int* au = reinterpret_cast<const int*>(a.audio) + (size_t)b * a.Tp;
             int idxs[8];
             for (int k = 0; k < K && k < 8; ++k) {
@@ -1318,7 +1339,10 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     float* wup_part = (!hs_bf16 && !drop) ? dxm : nullptr;
     if (wup_part && hipMemsetAsync(wup_part, 0, (size_t)SWN_WUP_COPIES * 256 * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
-    if (!hs_bf16 && hipMemsetAsync(dhs, 0, (size_t)B * (L + 1) * H * Tp * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
+    // Only level 0 needs zeros: levels 1..L are written whole by the skip data gradient below (accumulate = 0) before anything
+    // is added to them; d h_0 only ever receives additions.  (Zeroing all L + 1 levels was 710 MB = 0.11 ms per step at REF6.)
+    // (hipMemset2DAsync's fill kernel took 273 us for these 8 rows of 12.7 MB; a plain grid-stride store kernel is at the HBM rate)
+    if (!hs_bf16) hipLaunchKernelGGL(zero_rows_kernel, dim3(512, B), dim3(256), 0, st, dhs, (size_t)(L + 1) * H * Tp, (size_t)H * Tp);
     const long hsb = (long)(L + 1) * H * Tp;
 
     // ---- head: out_2, out_1, skip
