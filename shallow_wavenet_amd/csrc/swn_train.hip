@@ -370,6 +370,7 @@ struct ReduceGemm {
     const float* qmul; long qm_sb, qm_sc;           // optional: Q[b][c][t] is read as Q * qmul[b][c][t]
     int QT;                                         // Q is valid on [0, QT) (0: same as T)
     int nsegtot;                                    // batch * time segments (set by the launcher)
+    const unsigned short* P16; long p16_sb, p16_sm; // optional bf16 copy of P (rows 16-byte aligned, readable up to the next multiple of 32)
 };
 
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
@@ -535,6 +536,10 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16_kernel(const ReduceGemm 
 // loaded MFMA fragments straight from HBM into registers, no LDS at all - bound by the L1 path, every wave fetching its
 // own copy: 64 KB per step against 256 MFMA cycles).  A thread fetches 16-byte time-quads (8 lanes = one 128-byte row segment), rounds them to bf16 and stores
 // 8 bytes into LDS; double-buffered, one barrier per step of 32 positions.
+// P16: the P operand comes from its bf16 copy (g.P16: eight positions per 16-byte load, no conversion, half the bytes in
+// flight per step - the kernel waits on memory round trips, not on the matrix cores); the row sums of the bias gradient are
+// then sums of the rounded values.
+template <bool P16>
 __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm g) {
     __shared__ __attribute__((aligned(16))) unsigned Ps[2][128][SWN_MMB_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned Qs[2][128][SWN_MMB_PITCH];
@@ -556,6 +561,12 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
     const int QT = g.QT ? g.QT : g.T;
     const int smax = (g.taps - 1) * g.dil;
     const int q4 = tid & 7, r0 = tid >> 3;                  // staging: time-quad q4 of rows / columns r0 + 32 i
+    const __amdgpu_buffer_rsrc_t rP16 = rsrc_of(P16 ? g.P16 + (size_t)b * g.p16_sb : nullptr);
+    const int p8 = tid & 3, pr0 = tid >> 2;                 // P16 staging: time-octet p8 of rows pr0 + 64 i
+    unsigned prow16[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int m = m0 + pr0 + 64 * i; prow16[i] = m < g.M ? (unsigned)(m * g.p16_sm * 2) : SWN_OOB; }
+    const bool want_rs = g.gb && by == 0;
     unsigned prow[4], qrow[4]; int qsh[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -569,10 +580,16 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
     swn_f32x4 acc[4][4] = {};
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     swn_fl4 ra[2][4], rb[2][4];              // two steps of operands in flight (HBM latency is ~10 steps of MFMA work)
+                                             // (P16: ra[.][0..1] hold the two 16-byte octets of bf16 bits)
     auto load_fast = [&](int t, swn_fl4 (&ra)[4], swn_fl4 (&rb)[4]) {
         const unsigned to = (unsigned)((t + 4 * q4) * 4);
+        if (P16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ra[i] = bld4(rP, prow[i] + to);
+            for (int i = 0; i < 2; ++i) ra[i] = bld4(rP16, prow16[i] + (unsigned)((t + 8 * p8) * 2));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = bld4(rP, prow[i] + to);
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) rb[i] = bld4(rQ, qrow[i] + to);
     };
@@ -585,18 +602,45 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
                 const bool okp = te < tend;
                 const int tsrc = te + qsh[i];
                 const bool okq = okp && tsrc >= 0 && tsrc < QT && qrow[i] != SWN_OOB;
-                ra[i][e] = bld1(rP, okp ? prow[i] + (unsigned)(te * 4) : SWN_OOB);
+                if (!P16) ra[i][e] = bld1(rP, okp ? prow[i] + (unsigned)(te * 4) : SWN_OOB);
                 rb[i][e] = bld1(rQ, okq ? qrow[i] + (unsigned)(te * 4) : SWN_OOB);
             }
+        if (P16) {      // whole octets (the copy's rows are readable up to the next multiple of 32), positions >= tend masked off
+            const int nv = tend - (t + 8 * p8);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const swn_fl4 v = bld4(rP16, nv > 0 ? prow16[i] + (unsigned)((t + 8 * p8) * 2) : SWN_OOB);
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const unsigned mk = 2 * d + 1 < nv ? 0xffffffffu : (2 * d < nv ? 0x0000ffffu : 0u);
+                    ra[i][d] = __uint_as_float(__float_as_uint(v[d]) & mk);
+                }
+            }
+        }
     };
     auto stage = [&](int buf, const swn_fl4 (&ra)[4], const swn_fl4 (&rb)[4]) {
         typedef unsigned u2 __attribute__((ext_vector_type(2)));
+        if (P16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                if (want_rs) {
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const unsigned u = __float_as_uint(ra[i][d]);
+                        rs[i] += __uint_as_float(u << 16) + __uint_as_float(u & 0xffff0000u);
+                    }
+                }
+                *reinterpret_cast<swn_fl4*>(&Ps[buf][pr0 + 64 * i][4 * p8]) = ra[i];
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            rs[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
-            const u2 vp = {swn_pack_bf16(ra[i].x, ra[i].y), swn_pack_bf16(ra[i].z, ra[i].w)};
+            if (!P16) {
+                rs[i] += (ra[i].x + ra[i].y) + (ra[i].z + ra[i].w);
+                const u2 vp = {swn_pack_bf16(ra[i].x, ra[i].y), swn_pack_bf16(ra[i].z, ra[i].w)};
+                *reinterpret_cast<u2*>(&Ps[buf][r0 + 32 * i][2 * q4]) = vp;
+            }
             const u2 vq = {swn_pack_bf16(rb[i].x, rb[i].y), swn_pack_bf16(rb[i].z, rb[i].w)};
-            *reinterpret_cast<u2*>(&Ps[buf][r0 + 32 * i][2 * q4]) = vp;
             *reinterpret_cast<u2*>(&Qs[buf][r0 + 32 * i][2 * q4]) = vq;
         }
     };
@@ -641,7 +685,16 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
     }
     for (int sidx = sb; sidx < nsteps; ++sidx) { load_edge(ts0 + 32 * sidx, ra[0], rb[0]); stage(0, ra[0], rb[0]); __syncthreads(); mma(0); __syncthreads(); }
 
-    if (g.gb && by == 0) {          // bias gradient: a row's eight time-quads sit in eight neighbouring lanes
+    if (P16 && want_rs) {           // a row's four time-octets sit in four neighbouring lanes
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float v = rs[i];
+            v += __shfl_xor(v, 1); v += __shfl_xor(v, 2);
+            const int m = m0 + pr0 + 64 * i;
+            if (p8 == 0 && m < g.M) atomicAdd(g.gb + m, v);
+        }
+    }
+    if (!P16 && g.gb && by == 0) {  // bias gradient: a row's eight time-quads sit in eight neighbouring lanes
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v = rs[i];
@@ -679,6 +732,7 @@ struct GateBwd {
     const float* in_mul;   // (B, H, Tp) mask on this layer's INPUT h_{l-1}: it was the dropped output of layer l-1
     float* gwxa;           // softmax audio_in: gradient of the one-hot columns of in_x, [L][Q][2H] (packed wxa section)
     const float* a_in;     // gate pre-activations to read (null: a_da, where the recompute GEMM just left them)
+    unsigned short* da16; long da16_pitch;     // optional bf16 copy of da, rows of da16_pitch elements (weight-gradient operand)
 };
 
 template <int KIND>
@@ -724,6 +778,11 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     const float dz = dh * (hprev - c) * z * (1.f - z);      // d/d(gz*sz)
     const float dc = dh * (1.f - z) * (1.f - c * c);        // d/d(gc*sc)
     *az = dz * gz; *ac = dc * gc;                           // da
+    if (a.da16) {
+        const unsigned pk = swn_pack_bf16(dz * gz, dc * gc);
+        a.da16[((size_t)b * H2 + o) * a.da16_pitch + t] = (unsigned short)(pk & 0xffffu);
+        a.da16[((size_t)b * H2 + H + o) * a.da16_pitch + t] = (unsigned short)(pk >> 16);
+    }
     a.dgx[((size_t)b * H2 + o) * a.Tp + t] = dz * sz;
     a.dgx[((size_t)b * H2 + H + o) * a.Tp + t] = dc * sc;
     if (KIND == SWN_KIND_SOFTMAX && g.audio_in && a.gwxa) {      // one-hot input column idx: d in_x.W[o][A0+idx] += dgx
@@ -1048,7 +1107,9 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
             const int ns = (g.T + g.TS - 1) / g.TS;
             {
                 g.nsegtot = B * ns;
-                hipLaunchKernelGGL(reduce_gemm_bf16s_kernel, dim3((unsigned)(mt * nt * ((g.nsegtot + 7) / 8) * 8)), dim3(256), 0, st, g);
+                const dim3 rgrid((unsigned)(mt * nt * ((g.nsegtot + 7) / 8) * 8));
+                if (g.P16) hipLaunchKernelGGL(reduce_gemm_bf16s_kernel<true>, rgrid, dim3(256), 0, st, g);
+                else hipLaunchKernelGGL(reduce_gemm_bf16s_kernel<false>, rgrid, dim3(256), 0, st, g);
             }
             return;
         }
@@ -1077,7 +1138,8 @@ extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int
     size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
     return r64((size_t)batch * g.O1 * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * (g.L + 1) * g.H * Tp) +
            2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) +
-           (size_t)SWN_WUP_COPIES * 256;       // partial upsampler-tap gradients of cond_bwd_kernel
+           (size_t)SWN_WUP_COPIES * 256 +     // partial upsampler-tap gradients of cond_bwd_kernel
+           r64((size_t)batch * 2 * g.H * ((Tp + 31) & ~31L) / 2);      // bf16 copy of a layer's da (mixed-precision weight gradients)
 }
 
 namespace {
@@ -1218,7 +1280,7 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const GateBwd a, float* _
 int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const float* packed, const void* audio, const float* gx,
                                   const float* const* drop_h, float* hs, float* a_scr, float* hmask, int B, int n_frames, int Tp,
                                   hipStream_t st) {
-    GateBwd ga;
+    GateBwd ga{};
     ga.g = g; ga.y = y; ga.P = packed; ga.cond = nullptr; ga.audio = audio; ga.hs = hs; ga.dhs = nullptr; ga.a_da = a_scr;
     ga.dgx = nullptr; ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
     ga.gx = gx; ga.gwxa = nullptr; ga.a_in = nullptr;
@@ -1278,7 +1340,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
                   const float* drop_x, const float* const* drop_h,
                   const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_,
                   const char* where, const void* hs_bf16 = nullptr, const float* a_keep = nullptr) {
-    GateBwd ga;
+    GateBwd ga{};
     int rc = swn_make_geom(d, &ga.g);
     if (rc < 0) return rc;
     const SwnGeom& g = ga.g;
@@ -1337,6 +1399,12 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // teacher-forced chain without dropout: the partial g w_up copies of cond_bwd_kernel sit where the dropout mode keeps dxm
     float* wup_part = (!hs_bf16 && !drop) ? dxm : nullptr;
+    // mixed-precision chain: gate_bwd also leaves da as bf16 rows (pitch = Tp rounded up to 32) for the layer weight gradients
+    const long da16_pitch = (Tp + 31) & ~31L;
+    unsigned short* da16 = nullptr;
+    if (!hs_bf16 && g_train_bf16.load(std::memory_order_relaxed) == 1)
+        da16 = reinterpret_cast<unsigned short*>(drop ? hmask + r64((size_t)B * H * Tp) : dxm + (size_t)SWN_WUP_COPIES * 256);
+    ga.da16 = da16; ga.da16_pitch = da16_pitch;
     if (wup_part && hipMemsetAsync(wup_part, 0, (size_t)SWN_WUP_COPIES * 256 * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
     // Only level 0 needs zeros: levels 1..L are written whole by the skip data gradient below (accumulate = 0) before anything
@@ -1411,6 +1479,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             ReduceGemm r = {a_da, (long)H2 * Tp, Tp, 1, xin, xin_sb, Tp, 1,
                             gpacked + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, gpacked + y.bd + (size_t)l * H2,
                             H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
+            r.P16 = da16; r.p16_sb = (long)H2 * da16_pitch; r.p16_sm = da16_pitch;
             launch_reduce(r, B, st);
         }
         {   // dh_{l-1} += Wd^T (*) da  (taps shifted forward): A(m=i, tap, c=o2) = Wd[o2][tap][i]
