@@ -36,6 +36,11 @@ struct TimeGemm {
     const float* bias; int relu;                    // optional: v = acc + bias[m], then max(v, 0)  (forward 1x1 layers)
     int ksplit;                                     // > 1 (bf16 64x64 kernel only): the k range is cut into ksplit parts, one per
                                                     // workgroup, added atomically into a zeroed Y (frame-rate GEMMs: few tiles, long k)
+    // optional bf16 operands (time_gemm_b16_kernel: data gradients of the mixed-precision chain)
+    const unsigned short* A16; long a16_sm, a16_stap;   // A(m, tap, c) = A16[tap * a16_stap + m * a16_sm + c]  (c contiguous)
+    const unsigned short* X16; long x16_sb, x16_sc, x16_odd;   // X[b][c][t] = X16[b * x16_sb + c * x16_sc + t], and x16_odd elements on a
+                                                    // second copy moved right by one position (copy[u] = X[u - 1]): a pair
+                                                    // (t, t + 1) shifted by any tap is then one aligned dword of one of the two
 };
 
 // Epilogue of the time contractions: relu mask, dropout multiplier, accumulate, store - for NV results of one thread.
@@ -364,6 +369,121 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * i + e] = acc[i][j][e];
         tg_epilogue<16>(g, b, mrow, t0 + 64 * wn + 16 * j + rc, v);
+    }
+}
+
+
+// Data gradients with BOTH operands in bf16 (mixed-precision chain at the GEMM-stack geometries): A from a transposed bf16 copy of
+// the layer matrix (16-byte loads of eight k straight into LDS), X from gate_bwd's two bf16 copies of da (a thread owns the
+// column pair (2 tp, 2 tp + 1) of eight k rows: eight dword loads per k-tile, two byte-permutes per LDS store).  24 operand
+// registers per thread instead of 64 put THREE workgroups on a CU (launch bound) - these loops wait on memory round trips, and
+// what fewer bytes buy is workgroups in flight (bf16 X alone, registers unchanged, had gained nothing).
+__global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g) {
+    __shared__ __attribute__((aligned(16))) unsigned As2[2][128][SWN_MMB_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned Bs2[2][128][SWN_MMB_PITCH];
+    const int ntt = (g.T + 127) / 128, mtl = (g.M + 127) / 128;
+    const int chunk = (ntt * g.nb + 7) / 8;
+    const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int ttl = idx / mtl, mtile = idx - ttl * mtl;
+    const int gt = xcd * chunk + ttl;
+    if (ttl >= chunk || gt >= ntt * g.nb) return;
+    const int b = gt / ntt, t0 = (gt - b * ntt) * 128, m0 = mtile * 128;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.A16), 0, 0x40000000, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rX = rsrc_of(g.X16 + (size_t)b * g.x16_sb);
+    const int ntiles = g.taps * (g.KC / 32);
+    swn_f32x4 acc[4][4] = {};
+    const int XT = g.XT ? g.XT : g.T;
+    const int a8 = tid & 3, ar0 = tid >> 2;                    // A: k-octet a8 of rows ar0, ar0 + 64
+    unsigned arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int m = m0 + ar0 + 64 * i; arow[i] = m < g.M ? (unsigned)((m * g.a16_sm + 8 * a8) * 2) : SWN_OOB_A; }
+    const int tp = tid & 63, kw = tid >> 6;                    // X: column pair tp, k-quads kw and kw + 4
+    const unsigned rs2 = (unsigned)(g.x16_sc * 2);
+    int ftap = 0, fc0 = 0;
+    swn_fl4 ra[2][2]; unsigned rb[2][8];
+    auto fetch = [&](swn_fl4 (&qa)[2], unsigned (&qb)[8]) {
+        const bool live = fc0 < g.KC;
+        const unsigned sA = live ? (unsigned)((ftap * g.a16_stap + fc0) * 2) : SWN_OOB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) qa[i] = bld4(rA, arow[i] + sA);
+        const int sh = g.sgn * (ftap - g.center) * g.dil, par = sh & 1;
+        const int ts = t0 + 2 * tp + sh;                                       // source positions ts, ts + 1
+        const bool ok0 = live && ts >= 0 && ts < XT, ok1 = live && ts + 1 >= 0 && ts + 1 < XT;
+        // even shift: dword (ts, ts + 1) of the plain copy; odd: dword at index ts + 1 of the copy moved right by one
+        const unsigned base = (ok0 || ok1) ? (unsigned)(((par ? g.x16_odd + 1 : 0) + ts) * 2) : SWN_OOB;
+        const unsigned mk = (ok0 ? 0x0000ffffu : 0u) | (ok1 ? 0xffff0000u : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                qb[4 * i + e] = __float_as_uint(bld1(rX, base + (unsigned)(fc0 + 4 * (kw + 4 * i) + e) * rs2)) & mk;
+        if (++ftap >= g.taps) { ftap = 0; fc0 += 32; }         // taps innermost, as in time_gemm_bf16t_kernel
+    };
+    auto stage = [&](int buf, const swn_fl4 (&qa)[2], const unsigned (&qb)[8]) {
+        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<swn_fl4*>(&As2[buf][ar0 + 64 * i][4 * a8]) = qa[i];
+            const unsigned d0 = qb[4 * i], d1 = qb[4 * i + 1], d2 = qb[4 * i + 2], d3 = qb[4 * i + 3];   // d_e = (x[k e][2 tp], x[k e][2 tp + 1])
+            const u2 lo = {(d0 & 0xffffu) | (d1 << 16), (d2 & 0xffffu) | (d3 << 16)};
+            const u2 hi = {(d0 >> 16) | (d1 & 0xffff0000u), (d2 >> 16) | (d3 & 0xffff0000u)};
+            *reinterpret_cast<u2*>(&Bs2[buf][2 * tp][2 * (kw + 4 * i)]) = lo;
+            *reinterpret_cast<u2*>(&Bs2[buf][2 * tp + 1][2 * (kw + 4 * i)]) = hi;
+        }
+    };
+    auto mma = [&](int buf) {
+        const int kq = lane >> 4, rc = lane & 15;
+        swn_bf16x8 fa[4], fb[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            fa[i] = *reinterpret_cast<const swn_bf16x8*>(&As2[buf][64 * wm + 16 * i + rc][4 * kq]);
+            fb[i] = *reinterpret_cast<const swn_bf16x8*>(&Bs2[buf][64 * wn + 16 * i + rc][4 * kq]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+    fetch(ra[0], rb[0]);
+    fetch(ra[1], rb[1]);
+    for (int j = 0; j < ntiles; j += 2) {                      // a tile past the end is all zeros
+        stage(0, ra[0], rb[0]);
+        __syncthreads();                                       // every wave is past the MFMAs that read this buffer two tiles ago
+        fetch(ra[0], rb[0]);
+        mma(0);
+        stage(1, ra[1], rb[1]);
+        __syncthreads();
+        fetch(ra[1], rb[1]);
+        mma(1);
+    }
+    const int kq = lane >> 4, rc = lane & 15;
+    int mrow[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) mrow[4 * i + e] = m0 + 64 * wm + 16 * i + 4 * kq + e;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[4 * i + e] = acc[i][j][e];
+        tg_epilogue<16>(g, b, mrow, t0 + 64 * wn + 16 * j + rc, v);
+    }
+}
+
+// transposed bf16 copy of the dilated-conv matrices for time_gemm_b16_kernel: dst[l][tap][i][o2] = Wd[l][o2][tap][i]
+__global__ __launch_bounds__(256) void wd_t16_kernel(const float* __restrict__ wd, unsigned short* __restrict__ dst, const int L,
+                                                     const int K, const int H, const int Hp) {
+    const int H2 = 2 * H;
+    const size_t n = (size_t)L * K * H * H2;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (size_t)gridDim.x * 256) {
+        const int o2 = (int)(e % H2); size_t r = e / H2;
+        const int i = (int)(r % H); r /= H;
+        const int tap = (int)(r % K); const int l = (int)(r / K);
+        dst[e] = (unsigned short)(swn_pack_bf16(wd[(((size_t)l * H2 + o2) * K + tap) * Hp + i], 0.f) & 0xffffu);
     }
 }
 
@@ -738,7 +858,9 @@ struct GateBwd {
     const float* in_mul;   // (B, H, Tp) mask on this layer's INPUT h_{l-1}: it was the dropped output of layer l-1
     float* gwxa;           // softmax audio_in: gradient of the one-hot columns of in_x, [L][Q][2H] (packed wxa section)
     const float* a_in;     // gate pre-activations to read (null: a_da, where the recompute GEMM just left them)
-    unsigned short* da16; long da16_pitch;     // optional bf16 copy of da, rows of da16_pitch elements (weight-gradient operand)
+    unsigned short* da16; long da16_pitch;     // optional bf16 copies of da, rows of da16_pitch elements: the plain one (weight-
+    long da16_odd;                             // gradient P operand) and, da16_odd elements on, one moved right by a position
+                                               // (with the plain one: the data gradient's X operand, TimeGemm::X16)
 };
 
 template <int KIND>
@@ -786,8 +908,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     *az = dz * gz; *ac = dc * gc;                           // da
     if (a.da16) {
         const unsigned pk = swn_pack_bf16(dz * gz, dc * gc);
-        a.da16[((size_t)b * H2 + o) * a.da16_pitch + t] = (unsigned short)(pk & 0xffffu);
-        a.da16[((size_t)b * H2 + H + o) * a.da16_pitch + t] = (unsigned short)(pk >> 16);
+        unsigned short* rz = a.da16 + ((size_t)b * H2 + o) * a.da16_pitch + t;
+        unsigned short* rc = a.da16 + ((size_t)b * H2 + H + o) * a.da16_pitch + t;
+        rz[0] = (unsigned short)(pk & 0xffffu); rz[a.da16_odd + 1] = (unsigned short)(pk & 0xffffu);
+        rc[0] = (unsigned short)(pk >> 16); rc[a.da16_odd + 1] = (unsigned short)(pk >> 16);
     }
     a.dgx[((size_t)b * H2 + o) * a.Tp + t] = dz * sz;
     a.dgx[((size_t)b * H2 + H + o) * a.Tp + t] = dc * sc;
@@ -1064,7 +1188,8 @@ void launch_time(const TimeGemm& g, int B, hipStream_t st) {
             h.nb = B;
             const int chunk = (((g.T + 127) / 128) * B + 7) / 8;
             const dim3 big((unsigned)(8 * chunk * ((g.M + 127) / 128)));
-            if (g.a_sc == 1) hipLaunchKernelGGL(time_gemm_bf16t_kernel<true>, big, dim3(256), 0, st, h);
+            if (g.A16 && g.X16 && !g.mask) hipLaunchKernelGGL(time_gemm_b16_kernel, big, dim3(256), 0, st, h);
+            else if (g.a_sc == 1) hipLaunchKernelGGL(time_gemm_bf16t_kernel<true>, big, dim3(256), 0, st, h);
             else hipLaunchKernelGGL(time_gemm_bf16t_kernel<false>, big, dim3(256), 0, st, h);
             return;
         }
@@ -1145,7 +1270,8 @@ extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int
     return r64((size_t)batch * g.O1 * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * (g.L + 1) * g.H * Tp) +
            2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) +
            (size_t)SWN_WUP_COPIES * 256 +     // partial upsampler-tap gradients of cond_bwd_kernel
-           r64((size_t)batch * 2 * g.H * ((Tp + 31) & ~31L) / 2);      // bf16 copy of a layer's da (mixed-precision weight gradients)
+           r64((size_t)batch * 2 * g.H * ((Tp + 2 + 31) & ~31L)) +     // two bf16 copies of a layer's da (mixed-precision GEMM operands)
+           r64((size_t)g.L * g.K * g.H * 2 * g.H / 2);                 // transposed bf16 copy of the layer matrices (data gradients)
 }
 
 namespace {
@@ -1406,11 +1532,16 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     // teacher-forced chain without dropout: the partial g w_up copies of cond_bwd_kernel sit where the dropout mode keeps dxm
     float* wup_part = (!hs_bf16 && !drop) ? dxm : nullptr;
     // mixed-precision chain: gate_bwd also leaves da as bf16 rows (pitch = Tp rounded up to 32) for the layer weight gradients
-    const long da16_pitch = (Tp + 31) & ~31L;
+    const long da16_pitch = (Tp + 2 + 31) & ~31L, da16_odd = (long)B * H2 * da16_pitch;
     unsigned short* da16 = nullptr;
     if (!hs_bf16 && g_train_bf16.load(std::memory_order_relaxed) == 1)
         da16 = reinterpret_cast<unsigned short*>(drop ? hmask + r64((size_t)B * H * Tp) : dxm + (size_t)SWN_WUP_COPIES * 256);
-    ga.da16 = da16; ga.da16_pitch = da16_pitch;
+    ga.da16 = da16; ga.da16_pitch = da16_pitch; ga.da16_odd = da16_odd;
+    unsigned short* wdt16 = nullptr;             // [l][tap][i][o2]
+    if (da16 && g.Hp == H && H2 % 32 == 0) {
+        wdt16 = da16 + 2 * r64((size_t)B * H2 * da16_pitch);
+        hipLaunchKernelGGL(wd_t16_kernel, dim3(1024), dim3(256), 0, st, packed + y.wd, wdt16, L, g.K, H, g.Hp);
+    }
     if (wup_part && hipMemsetAsync(wup_part, 0, (size_t)SWN_WUP_COPIES * 256 * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
     // Only level 0 needs zeros: levels 1..L are written whole by the skip data gradient below (accumulate = 0) before anything
@@ -1492,6 +1623,10 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             TimeGemm t = {Wd, 1, g.Hp, (long)g.K * g.Hp, a_da, (long)H2 * Tp, Tp, 1, dhs + (size_t)l * H * Tp, hsb, Tp, nullptr, 0, 0,
                           H, g.K, H2, Tp, -1, g.K - 1, g.dil[l], 1};
             t.ymul = in_mul; t.ym_sb = (long)H * Tp; t.ym_sm = Tp;
+            if (wdt16) {
+                t.A16 = wdt16 + (size_t)l * g.K * H * H2; t.a16_sm = H2; t.a16_stap = (long)H * H2;
+                t.X16 = da16; t.x16_sb = (long)H2 * da16_pitch; t.x16_sc = da16_pitch; t.x16_odd = da16_odd;
+            }
             launch_time(t, B, st);
         }
         if (!drop) {
