@@ -859,8 +859,9 @@ struct GateBwd {
     float* gwxa;           // softmax audio_in: gradient of the one-hot columns of in_x, [L][Q][2H] (packed wxa section)
     const float* a_in;     // gate pre-activations to read (null: a_da, where the recompute GEMM just left them)
     unsigned short* da16; long da16_pitch;     // optional bf16 copies of da, rows of da16_pitch elements: the plain one (weight-
-    long da16_odd;                             // gradient P operand) and, da16_odd elements on, one moved right by a position
-                                               // (with the plain one: the data gradient's X operand, TimeGemm::X16)
+    long da16_odd; int skip_da32;              // gradient P operand) and, da16_odd elements on, one moved right by a position
+                                               // (with the plain one: the data gradient's X operand, TimeGemm::X16);
+                                               // skip_da32: both GEMMs read the copies, the fp32 da is not stored
 };
 
 template <int KIND>
@@ -905,7 +906,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     const float z = sigm(gz * sz), c = tanhf(gc * sc);
     const float dz = dh * (hprev - c) * z * (1.f - z);      // d/d(gz*sz)
     const float dc = dh * (1.f - z) * (1.f - c * c);        // d/d(gc*sc)
-    *az = dz * gz; *ac = dc * gc;                           // da
+    if (!a.skip_da32) { *az = dz * gz; *ac = dc * gc; }     // da
     if (a.da16) {
         const unsigned pk = swn_pack_bf16(dz * gz, dc * gc);
         unsigned short* rz = a.da16 + ((size_t)b * H2 + o) * a.da16_pitch + t;
@@ -1541,6 +1542,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     if (da16 && g.Hp == H && H2 % 32 == 0) {
         wdt16 = da16 + 2 * r64((size_t)B * H2 * da16_pitch);
         hipLaunchKernelGGL(wd_t16_kernel, dim3(1024), dim3(256), 0, st, packed + y.wd, wdt16, L, g.K, H, g.Hp);
+        // launch_reduce / launch_time take their bf16-copy kernels under exactly these conditions: nobody reads the fp32 da then
+        ga.skip_da32 = Tp >= 256 ? 1 : 0;
     }
     if (wup_part && hipMemsetAsync(wup_part, 0, (size_t)SWN_WUP_COPIES * 256 * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // (the fused layer path writes d h_0 whole and keeps the other carries in its own buffers)
