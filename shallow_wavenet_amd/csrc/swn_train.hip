@@ -1539,7 +1539,9 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         da16 = reinterpret_cast<unsigned short*>(drop ? hmask + r64((size_t)B * H * Tp) : dxm + (size_t)SWN_WUP_COPIES * 256);
     ga.da16 = da16; ga.da16_pitch = da16_pitch; ga.da16_odd = da16_odd;
     unsigned short* wdt16 = nullptr;             // [l][tap][i][o2]
-    if (da16 && g.Hp == H && H2 % 32 == 0) {
+    // (the kernel reaches the second da copy through a 32-bit byte offset from an utterance's rows: it must stay below 2 GiB,
+    //  else the data gradients keep their fp32 X operand)
+    if (da16 && g.Hp == H && H2 % 32 == 0 && ((size_t)da16_odd + (size_t)H2 * da16_pitch) * 2 < (1ull << 31)) {
         wdt16 = da16 + 2 * r64((size_t)B * H2 * da16_pitch);
         hipLaunchKernelGGL(wd_t16_kernel, dim3(1024), dim3(256), 0, st, packed + y.wd, wdt16, L, g.K, H, g.Hp);
         // launch_reduce / launch_time take their bf16-copy kernels under exactly these conditions: nobody reads the fp32 da then
