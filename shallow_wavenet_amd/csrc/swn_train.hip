@@ -497,6 +497,9 @@ struct ReduceGemm {
     int QT;                                         // Q is valid on [0, QT) (0: same as T)
     int nsegtot;                                    // batch * time segments (set by the launcher)
     const unsigned short* P16; long p16_sb, p16_sm; // optional bf16 copy of P (rows 16-byte aligned, readable up to the next multiple of 32)
+    const unsigned short* Q16; long q16_sb, q16_sc, q16_odd;   // optional (with P16): two bf16 copies of Q, the second q16_odd elements on and
+                                                    // moved right by one position (copy[u] = Q[u - 1]): an octet shifted by any tap
+                                                    // starts at an even element of one of them
 };
 
 __global__ __launch_bounds__(256) void reduce_gemm_kernel(const ReduceGemm g) {
@@ -665,7 +668,10 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16_kernel(const ReduceGemm 
 // P16: the P operand comes from its bf16 copy (g.P16: eight positions per 16-byte load, no conversion, half the bytes in
 // flight per step - the kernel waits on memory round trips, not on the matrix cores); the row sums of the bias gradient are
 // then sums of the rounded values.
-template <bool P16>
+// Q16 (with P16): Q too comes from bf16 copies - two of them, the second moved right by one position, so that an octet shifted
+// by any tap starts at an even element of one of the two (gate_bwd writes both for the layer's input): 341 -> 277 us per layer
+// at REF6 with three workgroups per CU (a launch bound of four - 128 registers, LDS exactly full - measured the same).
+template <bool P16, bool Q16 = false>
 __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm g) {
     __shared__ __attribute__((aligned(16))) unsigned Ps[2][128][SWN_MMB_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned Qs[2][128][SWN_MMB_PITCH];
@@ -703,6 +709,17 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
         qsh[i] = g.sgn * (tap - g.center) * g.dil;
         qrow[i] = n < Nc ? (unsigned)((c * g.q_sc + qsh[i]) * 4) : SWN_OOB;     // modular: may be "negative"
     }
+    // Q16: octet p8 of columns pr0 + 64 i; the row base holds the tap shift (even part) and the copy its parity selects
+    const __amdgpu_buffer_rsrc_t rQ16 = rsrc_of(Q16 ? g.Q16 + (size_t)b * g.q16_sb : nullptr);
+    unsigned qrow16[2]; int qsh16[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int n = n0 + pr0 + 64 * i;
+        const int tap = n / g.KC, c = n - tap * g.KC;
+        const int sft = g.sgn * (tap - g.center) * g.dil, par = sft & 1;
+        qsh16[i] = sft;
+        qrow16[i] = n < Nc ? (unsigned)((c * g.q16_sc + sft + par + (par ? g.q16_odd : 0)) * 2) : SWN_OOB;     // modular
+    }
     swn_f32x4 acc[4][4] = {};
     float rs[4] = {0.f, 0.f, 0.f, 0.f};
     swn_fl4 ra[2][4], rb[2][4];              // two steps of operands in flight (HBM latency is ~10 steps of MFMA work)
@@ -716,8 +733,13 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
 #pragma unroll
             for (int i = 0; i < 4; ++i) ra[i] = bld4(rP, prow[i] + to);
         }
+        if (Q16) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = bld4(rQ, qrow[i] + to);
+            for (int i = 0; i < 2; ++i) rb[i] = bld4(rQ16, qrow16[i] + (unsigned)((t + 8 * p8) * 2));
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rb[i] = bld4(rQ, qrow[i] + to);
+        }
     };
     auto load_edge = [&](int t, swn_fl4 (&ra)[4], swn_fl4 (&rb)[4]) {
 #pragma unroll
@@ -729,8 +751,20 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
                 const int tsrc = te + qsh[i];
                 const bool okq = okp && tsrc >= 0 && tsrc < QT && qrow[i] != SWN_OOB;
                 if (!P16) ra[i][e] = bld1(rP, okp ? prow[i] + (unsigned)(te * 4) : SWN_OOB);
-                rb[i][e] = bld1(rQ, okq ? qrow[i] + (unsigned)(te * 4) : SWN_OOB);
+                if (!Q16) rb[i][e] = bld1(rQ, okq ? qrow[i] + (unsigned)(te * 4) : SWN_OOB);
             }
+        if (Q16) {      // pair by pair: a dword of the selected copy holds the shifted positions (te, te + 1); invalid halves masked off
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int te = t + 8 * p8 + 2 * d, ts0 = te + qsh16[i];
+                    const bool k0 = te < tend && ts0 >= 0 && ts0 < QT && qrow16[i] != SWN_OOB;
+                    const bool k1 = te + 1 < tend && ts0 + 1 >= 0 && ts0 + 1 < QT && qrow16[i] != SWN_OOB;
+                    const unsigned mk = (k0 ? 0x0000ffffu : 0u) | (k1 ? 0xffff0000u : 0u);
+                    rb[i][d] = __uint_as_float(__float_as_uint(bld1(rQ16, (k0 || k1) ? qrow16[i] + (unsigned)(te * 2) : SWN_OOB)) & mk);
+                }
+        }
         if (P16) {      // whole octets (the copy's rows are readable up to the next multiple of 32), positions >= tend masked off
             const int nv = tend - (t + 8 * p8);
 #pragma unroll
@@ -766,8 +800,14 @@ __global__ __launch_bounds__(256) void reduce_gemm_bf16s_kernel(const ReduceGemm
                 const u2 vp = {swn_pack_bf16(ra[i].x, ra[i].y), swn_pack_bf16(ra[i].z, ra[i].w)};
                 *reinterpret_cast<u2*>(&Ps[buf][r0 + 32 * i][2 * q4]) = vp;
             }
-            const u2 vq = {swn_pack_bf16(rb[i].x, rb[i].y), swn_pack_bf16(rb[i].z, rb[i].w)};
-            *reinterpret_cast<u2*>(&Qs[buf][r0 + 32 * i][2 * q4]) = vq;
+            if (!Q16) {
+                const u2 vq = {swn_pack_bf16(rb[i].x, rb[i].y), swn_pack_bf16(rb[i].z, rb[i].w)};
+                *reinterpret_cast<u2*>(&Qs[buf][r0 + 32 * i][2 * q4]) = vq;
+            }
+        }
+        if (Q16) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) *reinterpret_cast<swn_fl4*>(&Qs[buf][pr0 + 64 * i][4 * p8]) = rb[i];
         }
     };
     auto mma = [&](int buf) {
@@ -862,6 +902,8 @@ struct GateBwd {
     long da16_odd; int skip_da32;              // gradient P operand) and, da16_odd elements on, one moved right by a position
                                                // (with the plain one: the data gradient's X operand, TimeGemm::X16);
                                                // skip_da32: both GEMMs read the copies, the fp32 da is not stored
+    unsigned short* h16; long h16_odd;         // optional: the layer's (masked) input as two bf16 copies like da16's (rows of
+                                               // da16_pitch elements): the weight gradient's Q operand (ReduceGemm::Q16)
 };
 
 template <int KIND>
@@ -907,6 +949,11 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
     const float dz = dh * (hprev - c) * z * (1.f - z);      // d/d(gz*sz)
     const float dc = dh * (1.f - z) * (1.f - c * c);        // d/d(gc*sc)
     if (!a.skip_da32) { *az = dz * gz; *ac = dc * gc; }     // da
+    if (a.h16) {
+        const unsigned short hu = (unsigned short)(swn_pack_bf16(hprev, 0.f) & 0xffffu);
+        unsigned short* rh = a.h16 + ((size_t)b * H + o) * a.da16_pitch + t;
+        rh[0] = hu; rh[a.h16_odd + 1] = hu;
+    }
     if (a.da16) {
         const unsigned pk = swn_pack_bf16(dz * gz, dc * gc);
         unsigned short* rz = a.da16 + ((size_t)b * H2 + o) * a.da16_pitch + t;
@@ -1240,7 +1287,8 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
             {
                 g.nsegtot = B * ns;
                 const dim3 rgrid((unsigned)(mt * nt * ((g.nsegtot + 7) / 8) * 8));
-                if (g.P16) hipLaunchKernelGGL(reduce_gemm_bf16s_kernel<true>, rgrid, dim3(256), 0, st, g);
+                if (g.P16 && g.Q16) hipLaunchKernelGGL((reduce_gemm_bf16s_kernel<true, true>), rgrid, dim3(256), 0, st, g);
+                else if (g.P16) hipLaunchKernelGGL(reduce_gemm_bf16s_kernel<true>, rgrid, dim3(256), 0, st, g);
                 else hipLaunchKernelGGL(reduce_gemm_bf16s_kernel<false>, rgrid, dim3(256), 0, st, g);
             }
             return;
@@ -1272,7 +1320,8 @@ extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int
            2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) +
            (size_t)SWN_WUP_COPIES * 256 +     // partial upsampler-tap gradients of cond_bwd_kernel
            r64((size_t)batch * 2 * g.H * ((Tp + 2 + 31) & ~31L)) +     // two bf16 copies of a layer's da (mixed-precision GEMM operands)
-           r64((size_t)g.L * g.K * g.H * 2 * g.H / 2);                 // transposed bf16 copy of the layer matrices (data gradients)
+           r64((size_t)g.L * g.K * g.H * 2 * g.H / 2) +               // transposed bf16 copy of the layer matrices (data gradients)
+           r64((size_t)batch * g.H * ((Tp + 2 + 31) & ~31L));          // two bf16 copies of a layer's input (weight gradients' Q operand)
 }
 
 namespace {
@@ -1538,6 +1587,12 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     if (!hs_bf16 && g_train_bf16.load(std::memory_order_relaxed) == 1)
         da16 = reinterpret_cast<unsigned short*>(drop ? hmask + r64((size_t)B * H * Tp) : dxm + (size_t)SWN_WUP_COPIES * 256);
     ga.da16 = da16; ga.da16_pitch = da16_pitch; ga.da16_odd = da16_odd;
+    // ... and the layer's (masked) input, for the weight gradient's Q operand; second copy within 32-bit reach as for da
+    const long h16_odd = (long)B * H * da16_pitch;
+    unsigned short* h16 = nullptr;
+    if (da16 && Tp >= 256 && ((size_t)h16_odd + (size_t)H * da16_pitch) * 2 < (1ull << 31))
+        h16 = da16 + 2 * r64((size_t)B * H2 * da16_pitch) + 2 * r64((size_t)L * g.K * H * H2 / 2);
+    ga.h16 = h16; ga.h16_odd = h16_odd;
     unsigned short* wdt16 = nullptr;             // [l][tap][i][o2]
     // (the kernel reaches the second da copy through a 32-bit byte offset from an utterance's rows: it must stay below 2 GiB,
     //  else the data gradients keep their fp32 X operand)
@@ -1622,6 +1677,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
                             gpacked + y.wd + (size_t)l * H2 * g.K * g.Hp, (long)g.K * g.Hp, g.Hp, 1, gpacked + y.bd + (size_t)l * H2,
                             H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
             r.P16 = da16; r.p16_sb = (long)H2 * da16_pitch; r.p16_sm = da16_pitch;
+            r.Q16 = h16; r.q16_sb = (long)H * da16_pitch; r.q16_sc = da16_pitch; r.q16_odd = h16_odd;
             launch_reduce(r, B, st);
         }
         {   // dh_{l-1} += Wd^T (*) da  (taps shifted forward): A(m=i, tap, c=o2) = Wd[o2][tap][i]
