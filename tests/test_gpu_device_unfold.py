@@ -1,6 +1,9 @@
 """GPU: swn_unfold_grads_device (one launch: packed-layout gradients -> the gradient of every parameter tensor) against
 the torch-op version of the same chain rule (nets/_autograd.py unfold_packed_grads) on a random packed buffer, for every
-geometry class; reductions run in double on the device and in fp32 in torch: 1e-5 relative per tensor."""
+geometry class; reductions run in double on the device and in fp32 in torch: 1e-5 relative per tensor.  The one exception is
+the scalar upsampling bias: per-workgroup double partial sums meet in ONE fp32 atomic each (768 of them at the run.sh
+geometry, in whatever order the workgroups finish), so it carries the rounding of that many fp32 additions - up to 2e-5 of
+its magnitude was seen over 30 poisoned-allocator repetitions (tools/dbg_unfold.py): 1e-4 for that element."""
 import numpy as np
 import pytest
 import torch
@@ -40,7 +43,8 @@ def test_device_unfold_matches_torch_ops(gpu_ok, name):
         r = ref[k].reshape(p.shape)
         assert g.shape == p.shape and g.is_contiguous()
         err = float((g - r).abs().max())
-        assert err <= 1e-5 * max(1.0, float(r.abs().max())), (name, k, err)
+        tol = 1e-4 if k == "upsampling.conv.bias" else 1e-5
+        assert err <= tol * max(1.0, float(r.abs().max())), (name, k, err)
 
 
 def test_conv2d_geometry_keeps_the_torch_path(gpu_ok):
