@@ -11,6 +11,15 @@
 // plus element-wise kernels for the gate, the rank-1 upsampler / hoisted in_x, the input layer and
 // the Laplace head.  Hidden states h_0..h_L saved by the forward are reused; the gate pre-activations
 // are recomputed (one extra conv GEMM per layer) instead of being stored.
+//
+// Mixed-precision mode (swn_train_set_precision(1)): the same chain with bf16 operands on the matrix cores -
+//   time_gemm_bf16t_kernel / reduce_gemm_bf16s_kernel   128 x 128 tiles, fp32 operands rounded on the way into LDS
+//   time_gemm_b16_kernel, reduce_gemm_bf16s_kernel<true, true>   the layer GEMMs of the GEMM-stack geometries with BOTH
+//       operands read as bf16: gate_bwd_kernel leaves da and the layer input as bf16 rows (two copies each, the second moved
+//       right by one position so that every tap shift lands on an aligned element), wd_t16_kernel the transposed matrices;
+//       what the smaller operands buy is a third workgroup per CU
+// and the pre-activations are read back where the forward of the same mode kept them (swn_backward_keep).  The BL6 class takes
+// the fused per-layer backward of csrc/swn_bwd_bl6.hip instead.
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include "swn_geom.hpp"
