@@ -9,13 +9,17 @@ weights) already resident in HBM, samples left in HBM.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--utts B] [--frames Tf] [--no-legs]
   N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+         or plainly `python bench.py --gpus N`: with WORLD_SIZE unset the script starts its N ranks itself (child
+         processes, before the parent makes any GPU call) and exits non-zero if any of them fails.
 
-Prints ONE JSON line (rank 0).  `roofline` prices the decode kernel against the HBM roof with the
+Prints ONE JSON line (rank 0), kept under 6 KB: every leg is numbers only (`ms`, `value`, `frac`, `bound`, `rtf`,
+`us_step`); what each leg measures, its unit, dominant kernel and pricing is in profiles/LEGS.md, keyed by leg name; the
+verbose per-leg dictionaries go to gpurun_out/bench_detail.json.  `roofline` prices the decode kernel against the HBM roof with the
 ALGORITHMIC bytes of SURVEY.md section 8(d); `cpu_baseline` times the CPU oracle (a port of the
 reference's per-step op structure, oracle/cpu_ref.py) on a bounded sample of the same workload.
 
-At N=1 the line also carries `legs`: every other BASELINE.json config measured in the same run, each
-with its workload, value, the kernel that dominates it and its own roofline:
+At every N the line carries the `cfg5` leg (64 utterances per rank x Tf=600: BASELINE configs[4] is 8 such ranks).
+At N=1 the line also carries `legs`: every other BASELINE.json config measured in the same run:
   cfg1 (softmax 16 kHz), cfg3 (seg=5, lpc=4), cfg5's 64-utterance per-GPU share, the run.sh-geometry
   (REF6) companions of cfg1/2/3/5, cfg4 (teacher-forced forward and full training step incl. Adam, BL6 and REF6,
   fp32 and bf16), and `batch_fast_generate` as a caller sees it (noise draw + launch + device->host copy).
@@ -29,16 +33,70 @@ import platform
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _free_port() -> int:
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def self_launch(argv) -> int:
+    """`python bench.py --gpus N` with WORLD_SIZE unset: start the N ranks as child processes (rank r = GPU r, the
+    torchrun environment contract, rendezvous on 127.0.0.1) and wait for them.  Runs before torch is imported, so
+    the parent never initialises a GPU.  Rank 0 inherits stdout (the one JSON line); the other ranks' stdout goes
+    to stderr.  -> 0 when every rank exited 0, otherwise the first non-zero exit code (the rest are terminated)."""
+    import subprocess
+    n = 1
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            n = int(argv[i + 1])
+        elif a.startswith("--gpus="):
+            n = int(a.split("=", 1)[1])
+    if n <= 1 or "WORLD_SIZE" in os.environ:
+        return -1                                        # nothing to launch: the caller runs as the only / a given rank
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    code = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            rc = p.poll()
+            if rc is None:
+                continue
+            live.remove(p)
+            if rc != 0 and code == 0:
+                code = rc if rc > 0 else 1
+                for q in live:                           # a failed rank leaves the others waiting in a collective
+                    q.terminate()
+        time.sleep(0.05)
+    return code
+
+
+if __name__ == "__main__":
+    _rc = self_launch(sys.argv[1:])
+    if _rc >= 0:
+        sys.exit(_rc)
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
 
 from shallow_wavenet_amd import config as C, dist as D, noise as NZ           # noqa: E402
 from shallow_wavenet_amd.runtime import HipNet, pack_state_dict, train_precision   # noqa: E402
 from shallow_wavenet_amd.synth import synth_aux, synth_state_dict              # noqa: E402
 
+METRIC = "decoded samples/sec (22.05 kHz Laplacian AR decode, whole job)"
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak
 MFMA_FP32_TFLOPS = 157.0         # fp32 matrix peak (exact-fp32 MFMA parity kernels)
@@ -147,9 +205,8 @@ def cpu_baseline(cfg: C.NetConfig, sd, frames: int = 20, runs: int = 3):
             "by_threads": {str(k): round(v, 1) for k, v in results.items()},
             "sample": f"cfg2 B=1 Tf={frames}: {n} generated samples after the {cfg.receptive_field}-position prologue, "
                       f"free-running oracle decode, median of {runs} runs",
-            "note": "the port drops the reference's two growing torch.cat buffers (O(T^2), cswnv_shift1.py:359-364,"
-                    "400-412), so it runs ~2.8x faster than the reference itself did on 8 container cores "
-                    "(418 samples/s, SURVEY.md section 6): the baseline is flattered, not the GPU"}
+            "note": "port without the reference's two growing torch.cat buffers: ~2.8x faster than the reference itself "
+                    "(418 samples/s on 8 container cores, SURVEY.md 6) - the baseline is flattered, not the GPU"}
 
 
 # ------------------------------------------------------------------------------------------- legs
@@ -307,6 +364,62 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
     return leg
 
 
+def compact(leg: dict) -> dict:
+    """numbers only (the line must stay under 6 KB; profiles/LEGS.md holds the prose, keyed by leg name):
+    ms = measured time of one pass, value = the leg's rate (unit in LEGS.md), us_step / rtf for decodes (steady-state
+    slope where the leg measures one), bound + frac = its roofline, frac_design = the BL6 step priced on its own streams."""
+    if "error" in leg:
+        return {"error": leg["error"][:120]}
+    out = {"ms": leg.get("kernel_ms", leg.get("ms")), "value": leg.get("value")}
+    if "us_per_step" in leg:
+        out["us_step"] = leg.get("steady_state_us_per_step", leg["us_per_step"])
+        out["rtf"] = leg.get("steady_state_real_time_factor", leg["real_time_factor_per_utterance"])
+    if "batch_fast_generate" in leg:
+        out["caller_wall_over_kernel"] = leg["batch_fast_generate"]["wall_over_kernel"]
+    if "ms_forward_backward_only" in leg:
+        out["ms_fwd_bwd"] = leg["ms_forward_backward_only"]
+    r = leg.get("roofline")
+    if r:
+        out["bound"], out["frac"] = r["bound"], r["frac"]
+    if "roofline_hbm" in leg:
+        out["frac_design"] = leg["roofline_hbm"]["frac"]
+    return out
+
+
+def cfg5_leg(dev, rank: int, world: int, reps: int = 2):
+    """BASELINE configs[4] as seen by this job: 64 utterances per rank x Tf = 600, CSWNV BL6 seg 1 / lpc 0, every rank
+    decoding its own utterances (no data-path collective); barrier + max over ranks like the headline.
+    value = samples of ALL ranks / that time."""
+    cfg = C.bl6_laplace(1, 0)
+    B, Tf = 64, 600
+    n_steps = Tf * cfg.U
+    sd = synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True)
+    packed = pack_state_dict(cfg, sd) if rank == 0 else None
+    net = HipNet(cfg, D.broadcast_packed(cfg, packed, dev), dev)
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf, seed=100 + rank)).to(dev)
+    noise = NZ.laplace_uniform(cfg, n_steps, B, generator=torch.Generator().manual_seed(100 + rank)).to(dev)
+    cond = net.frontend(aux)
+    net.decode(aux, n_steps, noise, cond=cond)
+    D.barrier(dev)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        cond = net.frontend(aux)
+        net.decode(aux, n_steps, noise, cond=cond)
+    torch.cuda.synchronize()
+    D.barrier(dev)
+    elapsed = D.max_over_ranks(time.perf_counter() - t0, dev) / reps
+    positions = n_steps + cfg.receptive_field
+    bpp = algorithmic_bytes_per_position(cfg, B)
+    return {"workload": f"cfg5: {world} rank(s) x 64 utterances x Tf=600 (66 000 samples each), CSWNV BL6 seg=1 lpc=0",
+            "utterances": B * world, "ms": round(elapsed * 1e3, 3), "kernel_ms": round(elapsed * 1e3, 3),
+            "us_per_step": round(elapsed * 1e6 / positions, 3),
+            "value": round(world * B * n_steps / elapsed, 1), "unit": "samples/s (all ranks)",
+            "real_time_factor_per_utterance": round(n_steps / elapsed / 22050.0, 2),
+            "roofline": _hbm(bpp * positions, elapsed * 1e3, kernel="decode_bl6_kernel (one workgroup per utterance)",
+                             algorithmic_bytes_per_position=round(bpp, 1), positions_per_launch=positions)}
+
+
 def run_legs(dev, quick: bool = False):
     legs = {}
 
@@ -326,8 +439,6 @@ def run_legs(dev, quick: bool = False):
         C.bl6_softmax(), dev, 1, 600, 16000, 2, "decode_bl6_kernel<softmax>", caller=True)
     add("cfg3", decode_leg, "cfg3: CSWNV BL6 seg=5 lpc=4 (multi-sample output + LP), 22.05 kHz, 1 utterance x Tf=600 (13 200 steps)",
         C.bl6_laplace(5, 4), dev, 1, 600, 22050, 3, "decode_bl6_kernel<seg5,lpc4>", caller=True)
-    add("cfg5_share", decode_leg, "cfg5 per-GPU share: 64 utterances x Tf=600, CSWNV BL6 seg=1 lpc=0 (one workgroup per utterance)",
-        bl6, dev, 64, 600, 22050, 2, "decode_bl6_kernel")
     # run.sh geometry (REF6: 3x2 layers, K=7, H=192/256): companions of cfg1/2/3/5, 440-step decodes (+690-position prologue)
     r_tf = 4
     stepped = "stepped decode: step_layer_kernel x L + rowvec_kernel x 2 (3 for the softmax head) + step_tail_kernel per step"
@@ -375,20 +486,44 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--utts", type=int, default=1, help="utterances per GPU (cfg2: 1; cfg5: 64)")
+    ap.add_argument("--utts", type=int, default=1, help="utterances per GPU of the headline (cfg2: 1)")
     ap.add_argument("--frames", type=int, default=600, help="conditioning frames per utterance")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--quick-legs", action="store_true", help="decode legs only")
+    ap.add_argument("--plan-only", action="store_true",
+                    help="no GPU work: join the process group (gloo), count the ranks, print the line's skeleton "
+                         "(what the CPU tests drive)")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "gpurun_out", "bench_detail.json"),
+                    help="where rank 0 writes the verbose per-leg dictionaries ('' = nowhere)")
     args = ap.parse_args()
 
+    if args.plan_only:
+        rank, world, local = D.init_from_env(backend="gloo")
+        seen = int(round(D.sum_over_ranks(1.0, "cpu")))
+        if world != args.gpus:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+        D.barrier()
+        if rank == 0:
+            print(json.dumps({"metric": METRIC, "value": None, "unit": "samples/s", "n_gpus": seen, "ranks_seen": seen,
+                              "plan_only": True, "shards": [len(x) for x in D.shard_utterances(range(64 * world), world)]}),
+                  flush=True)
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_env != args.gpus:
+        # reached only with WORLD_SIZE set by a launcher (self_launch handles the unset case): never print n_gpus != ranks
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world_env}")
     rank, world, local = D.init_from_env()
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
+    ranks_seen = int(round(D.sum_over_ranks(1.0, dev)))          # what RCCL actually connected
+    if ranks_seen != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the all-reduce saw {ranks_seen} rank(s)")
 
     cfg = C.bl6_laplace(seg=1, lpc=0)
     B, Tf = args.utts, args.frames
@@ -433,8 +568,8 @@ def main():
     positions = n_steps + cfg.receptive_field - cfg.seg + 1                # generation steps + prologue positions
     achieved = bytes_pos * positions / (kern_ms * 1e-3) / 1e9
     line = {
-        "metric": "decoded samples/sec (22.05 kHz Laplacian AR decode, whole job)",
-        "value": round(value, 1), "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "metric": METRIC,
+        "value": round(value, 1), "unit": "samples/s", "n_gpus": ranks_seen, "ranks_seen": ranks_seen, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic",
@@ -445,27 +580,43 @@ def main():
         "us_per_sample_step": round(kern_ms * 1e3 / positions, 3),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC_BYTES.get((B, Tf)),
+                     "traffic_src": "constant from an offline rocprofv3 --pmc pass (profiles/r02_pmc_hbm_traffic_decode.csv), "
+                                    "not read in this process",
                      "kernel": "decode_bl6_kernel", "kernel_ms": round(kern_ms, 3),
                      "algorithmic_bytes_per_position": round(bytes_pos, 1), "positions_per_launch": positions,
-                     "note": "latency-bound sequential chain; working set is L2/LDS/VGPR resident (SURVEY 7.3)"},
+                     "note": "latency-bound sequential chain; working set on-chip"},
+        "legs_doc": "profiles/LEGS.md (units, kernels, pricing per leg; frac_design = priced on the design's own stream bytes)",
     }
+    detail = {}
+    # cfg5 (64 utterances per rank) on every rank at every N: the scaling curve's second line
+    try:
+        detail["cfg5"] = cfg5_leg(dev, rank, world)
+    except Exception as e:                                          # noqa: BLE001
+        detail["cfg5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1:
         # auxiliary measurements: a failure there must not cost the headline line
         if not args.no_legs:
             t_legs = time.perf_counter()
-            line["legs"] = run_legs(dev, quick=args.quick_legs)
+            detail.update(run_legs(dev, quick=args.quick_legs))
             line["legs_wall_s"] = round(time.perf_counter() - t_legs, 1)
-            # kept for continuity with round 1's line: the fused residual-block stack at 64 x 16 500
-            if "cfg4_bl6_fwd_bf16_b64" in line["legs"]:
-                line["stack"] = line["legs"]["cfg4_bl6_fwd_bf16_b64"]
         if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(cfg, sd)
             except Exception as e:                                  # noqa: BLE001
                 line["cpu_baseline"] = {"value": None, "unit": "samples/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {type(e).__name__}: {e}"}
+    line["legs"] = {k: compact(v) for k, v in detail.items()}
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        if args.detail:
+            try:
+                os.makedirs(os.path.dirname(args.detail), exist_ok=True)
+                with open(args.detail, "w") as f:
+                    json.dump(dict(line, legs=detail), f, indent=1)
+            except OSError:
+                pass
+        out_line = json.dumps(line, separators=(",", ":"))
+        assert len(out_line) < 6000, len(out_line)
+        print(out_line, flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -14,8 +14,8 @@
  *   - `stream` is a hipStream_t passed as void* (NULL = default stream). Launches are
  *     asynchronous; nothing in here synchronises, allocates or frees device memory.
  *   - every function returns 0 on success or a negative SWN_E_* code;
- *     swn_strerror() maps it to text.  No global mutable state except the one process-wide switch
- *     swn_train_set_precision() (documented there); nothing reads the environment.
+ *     swn_strerror() maps it to text.  No global mutable state (the arithmetic mode of the training
+ *     entry points is an argument of each call, SWN_PRECISION_*); nothing reads the environment.
  */
 #ifndef SWN_HIP_H
 #define SWN_HIP_H
@@ -27,7 +27,19 @@
 extern "C" {
 #endif
 
-#define SWN_ABI_VERSION 2
+#define SWN_ABI_VERSION 3   /* 3: `precision` argument instead of a process-wide switch; swn_decode_io.rng_utt_ids_dev;
+                             *    decode variants 4 / 5 retired */
+
+/* arithmetic of the training contractions, an argument of every entry point it applies to
+ *   FP32: fp32 operands on the matrix cores (v_mfma_f32_16x16x4_f32), bit-compatible with an fmaf chain - the parity
+ *         mode every gradient fixture is checked in;
+ *   BF16: mixed precision - the same fp32 tensors in HBM, operands rounded to bf16 on their way into LDS,
+ *         v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what torch.autocast(bfloat16) would do to the reference's
+ *         conv forward / backward); gradients agree with FP32 to ~1e-2 relative per tensor.
+ * A forward and the backward that reads its work buffer must be given the same value (the BF16 dropout forward keeps
+ * gate pre-activations in the work buffer that the FP32 one does not). */
+#define SWN_PRECISION_FP32 0
+#define SWN_PRECISION_BF16 1
 
 #define SWN_KIND_LAPLACE 0   /* CSWNV, cswnv_shift1.py:130 */
 #define SWN_KIND_SOFTMAX 1   /* DSWNV, dswnv.py:190       */
@@ -136,7 +148,7 @@ typedef struct swn_decode_io {
      * generator in the reference's order): laplace (B, n_steps, seg) uniform(-0.4999, 0.5) draws
      * (cswnv_shift1.py:373,380,387), softmax (B, n_steps, Q) Exp(1) draws (the multinomial of dswnv.py:364-365).
      * noise_dev == NULL: the kernels draw the same quantities themselves with a counter-based generator
-     * (Philox4x32-10 keyed by rng_seed, counter = (rng_utt0 + b, step, element): csrc/swn_noise.hpp), like the
+     * (Philox4x32-10 keyed by rng_seed, counter = (global utterance index of b, step, element): csrc/swn_noise.hpp), like the
      * reference drawing on the model's device; nothing is drawn, stored or uploaded by the host. */
     const float* noise_dev;
     /* optional teacher forcing (may be NULL): laplace (B, n_steps*seg) fp32 samples, softmax (B, n_steps) int32
@@ -150,8 +162,12 @@ typedef struct swn_decode_io {
      * a device-drawn run in the CPU oracle ("given the same noise") */
     float*       noise_out_dev;
     uint64_t     rng_seed;      /* used when noise_dev == NULL */
-    uint32_t     rng_utt0;      /* global index of utterance 0: draws do not depend on batching or sharding */
+    uint32_t     rng_utt0;      /* global index of utterance 0 (utterance b draws as rng_utt0 + b) ... */
     uint32_t     reserved;      /* 0 */
+    /* ... or, when not NULL, (B) uint32 global utterance indices, one per utterance of the batch: a decode driver that
+     * sorts utterances by length into batches (decode_cswnv_laplace-shift1.py:77-84) passes each utterance's position in
+     * the unsorted list, so that the draws depend neither on batching nor on how the list is sharded over GPUs */
+    const uint32_t* rng_utt_ids_dev;
 } swn_decode_io;
 size_t swn_decode_state_floats(const swn_net_desc* d, int batch);
 int    swn_decode(const swn_net_desc* d, const float* packed_dev, const float* cond_dev,
@@ -194,10 +210,10 @@ int    swn_forward_bf16(const swn_net_desc* d, const float* packed_dev, const vo
  * of swn_forward (hidden states | relu(skip) | relu(out_1); swn_forward_work_floats() floats), so that swn_backward can
  * follow a bf16 forward of the same (cond, audio).  GEMM-stack class: all three are expanded from memory.  BL6 class:
  * the head kernel keeps the two activations on chip, so the hidden states are expanded and the two 1x1 products are
- * redone from them in the arithmetic of swn_train_set_precision (packed_dev is read only there).  _supported: 1 where swn_forward_bf16 exists, else 0. */
+ * redone from them in the arithmetic `precision` selects (packed_dev is read only there).  _supported: 1 where swn_forward_bf16 exists, else 0. */
 int    swn_bf16_train_forward_supported(const swn_net_desc* d);
 int    swn_bf16_work_to_f32(const swn_net_desc* d, const float* packed_dev, const void* work_bf16_dev, int batch,
-                            int n_frames, float* fwd_work_dev, void* stream);
+                            int n_frames, float* fwd_work_dev, int precision, void* stream);
 
 /* ---- Laplace output split  (cswnv_shift1.py:228-267) -----------------------------------
  * raw (B, n_out, Tp) from swn_forward  ->  time-major tensors the reference returns:
@@ -224,8 +240,8 @@ size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_backward(const swn_net_desc* d, const float* packed_dev, const float* aux_dev, const float* cond_dev,
                     const float* fe_work_dev, const void* audio_dev, const float* fwd_work_dev,
                     const float* hs_dev, const float* grad_out_dev, int batch, int n_frames,
-                    float* work_dev, float* gpacked_dev, void* stream);
-/* The same backward after a bf16 forward of the BL6 class in the mixed-precision mode (swn_train_set_precision(1)), with
+                    float* work_dev, float* gpacked_dev, int precision, void* stream);
+/* The same backward after a bf16 forward of the BL6 class, in the mixed-precision arithmetic (SWN_PRECISION_BF16) only, with
  * everything at sample rate fused (csrc/swn_bwd_bl6.hip): one launch for the head (recompute of relu(skip) / relu(out_1),
  * d out_1, d skip, g out_2), one per gated layer (the layer above's data gradient, the skip path's share, recompute, gate
  * derivative, highway carry, conditioning) plus one that also does the input layer, and one for every other weight
@@ -262,28 +278,20 @@ int    swn_backward_keep(const swn_net_desc* d, const float* packed_dev, const f
  *                hands to layer l+1 (its skip output is not masked), NULL where the reference does not drop
  * aux_drop acts at sample rate, so the frame-rate hoisting of in_x does not apply: in_x is evaluated as a
  * sample-rate GEMM on the masked conditioning (no cond_dev input; fe_work_dev = swn_frontend's work buffer).
- * fwd_work_dev of swn_backward_drop must be the buffer swn_forward_drop filled, and the arithmetic mode
- * (swn_train_set_precision) must be the same for both calls: in mode 1, for nets with hid_chn % 64 == 0, the forward keeps
- * every layer's gate pre-activations in that buffer and the backward reads them instead of recomputing them. */
+ * fwd_work_dev of swn_backward_drop must be the buffer swn_forward_drop filled, and `precision` must be the same for
+ * both calls: with SWN_PRECISION_BF16, for nets with hid_chn % 64 == 0, the forward runs its sample-rate in_x GEMM and, per
+ * layer, the dilated conv as a bf16-operand GEMM followed by an element-wise gate kernel (instead of the fused exact-fp32
+ * layer kernel) and keeps every layer's gate pre-activations in that buffer; the backward reads them instead of
+ * recomputing them. */
 size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_forward_drop(const swn_net_desc* d, const float* packed_dev, const float* fe_work_dev, const void* audio_dev,
                         int batch, int n_frames, const float* drop_x_dev, const float* const* drop_h_host,
-                        float* work_dev, float* out_dev, float* hs_dev, void* stream);
+                        float* work_dev, float* out_dev, float* hs_dev, int precision, void* stream);
 size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_backward_drop(const swn_net_desc* d, const float* packed_dev, const float* aux_dev, const float* fe_work_dev,
                          const void* audio_dev, const float* fwd_work_dev, const float* hs_dev,
                          const float* drop_x_dev, const float* const* drop_h_host, const float* grad_out_dev,
-                         int batch, int n_frames, float* work_dev, float* gpacked_dev, void* stream);
-/* ---- arithmetic of the backward contractions (process-wide switch) -------------------------------------------
- * mode 0 (default): fp32 operands on the matrix cores, bit-compatible with an fmaf chain - the parity mode the
- *                   gradient fixtures are checked in.
- * mode 1: mixed precision - the same fp32 tensors in HBM, operands rounded to bf16 on their way into LDS,
- *         v_mfma_f32_16x16x32_bf16 with fp32 accumulation (what torch.autocast(bfloat16) would do to the
- *         reference's conv backward); gradients agree with mode 0 to ~1e-2 relative per tensor.
- * Applies to swn_backward, swn_backward_drop and to swn_forward_drop (its sample-rate in_x GEMM and, per layer, the dilated
- * conv as a bf16-operand GEMM followed by an element-wise gate kernel instead of the fused exact-fp32 layer kernel). */
-int    swn_train_set_precision(int mode);
-int    swn_train_get_precision(void);
+                         int batch, int n_frames, float* work_dev, float* gpacked_dev, int precision, void* stream);
 /* gradient of swn_laplace_head: grads wrt mu / b / logb / a (time-major, any may be NULL) -> grad wrt raw */
 int    swn_laplace_head_backward(const swn_net_desc* d, const float* out_dev, int batch, int tp,
                                  const float* gmu_dev, const float* gb_dev, const float* glogb_dev,

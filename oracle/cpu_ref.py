@@ -174,10 +174,11 @@ def laplace_stack(cfg, P, aux: torch.Tensor, audio: torch.Tensor, drop=None):
     return head(cfg, P, tot), hs
 
 
-def laplace_forward(cfg, P, aux: torch.Tensor, audio: torch.Tensor, clip: bool = False):
-    """CSWNV.forward(aux, audio, do=False, clip) - same return tuples as the reference."""
+def laplace_forward(cfg, P, aux: torch.Tensor, audio: torch.Tensor, clip: bool = False, drop=None):
+    """CSWNV.forward(aux, audio, do, clip) - same return tuples as the reference; drop = explicit training-mode
+    masks as in laplace_stack (None = do=False / eval)."""
     seg = cfg.seg
-    out, _ = laplace_stack(cfg, P, aux, audio)
+    out, _ = laplace_stack(cfg, P, aux, audio, drop=drop)
     out = out.transpose(1, 2)
     mu = out[:, :, :seg]
     log_b = F.logsigmoid(out[:, :, seg:2 * seg])

@@ -334,10 +334,12 @@ def gen_softmax(name, cfg, frames, wseed, flavor, aux_seed, noise_seed, head_str
           f"min margin={margin.min():.2e}")
 
 
-def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p, do=True):
+def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p, do=True, big=False):
     """training-mode forward + backward WITH dropout (model.train(), do=True, do_prob=p): the masks the reference
     draws are re-derived with shallow_wavenet_amd.noise.dropout_masks from the same seed and checked through the
-    oracle against the reference's own outputs before anything is stored."""
+    oracle against the reference's own outputs before anything is stored.  big=True (G9: the geometries that are
+    actually trained, run.sh:165-198) stores gradients the way G7 does: whole up to 4096 elements, otherwise
+    digest + norm + the fixed 2048-element subset; logits additionally at every 16th position."""
     from shallow_wavenet_amd import noise as swn_noise
     t0 = time.time()
     mod = ref_d.DSWNV if cfg.kind == "softmax" else ref_c.CSWNV
@@ -384,16 +386,21 @@ def gen_dropout(name, cfg, frames, wseed, flavor, aux_seed, drop_seed, p, do=Tru
         out["fwd_logits_dig"] = digest(logits.detach().numpy())
         out["fwd_logits_head"] = logits.detach().numpy()[:, :64]
         out["fwd_logits_tail"] = logits.detach().numpy()[:, -64:]
+        if big:
+            out["fwd_logits_s16"] = logits.detach().numpy()[:, ::16]
         tgt = torch.from_numpy(rng.integers(0, Q, size=(B, T - 1)).astype(np.int64))
         loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, Q), tgt.reshape(-1))
     loss.backward()
     out["loss_target"] = tgt.numpy()
     out["loss"] = np.float64(loss.item())
-    for k, prm in m.named_parameters():
-        gnp = prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
-        out[f"gdig_{k}"] = digest(gnp)
-        if gnp.size <= 4096:
-            out[f"grad_{k}"] = gnp
+    if big:
+        _store_grads(out, m)
+    else:
+        for k, prm in m.named_parameters():
+            gnp = prm.grad.numpy() if prm.grad is not None else np.zeros(tuple(prm.shape), np.float32)
+            out[f"gdig_{k}"] = digest(gnp)
+            if gnp.size <= 4096:
+                out[f"grad_{k}"] = gnp
     np.savez_compressed(os.path.join(GOLD, name + ".npz"), **out)
     print(f"[golden] {name}: B={B} p={p} mask check err={err:.2e} loss={loss.item():.4f} {time.time() - t0:.1f}s")
 
@@ -643,6 +650,17 @@ def main():
                      dict(cfg=C.ref6_laplace(5, 4), frames=[9, 8], wseed=42, flavor="xavier", aux_seed=8)))
         jobs.append(("g7_ref6_tf_smx", gen_teacher_forced,
                      dict(cfg=C.ref6_softmax(), frames=[9, 7], wseed=43, flavor="xavier", aux_seed=8)))
+        # ---- G9: the training mode AS run.sh TRAINS (model.train(), forward(do=True), do_prob = 0.5, run.sh:198) at the
+        # geometries that are trained, through the reference with the CPU generator seeded (B = 2 ragged, ~990 positions)
+        jobs.append(("g9_drop_ref6_lap_s1l4", gen_dropout,
+                     dict(cfg=C.ref6_laplace(1, 4), frames=[9, 8], wseed=71, flavor="trained", aux_seed=12, drop_seed=81,
+                          p=0.5, big=True)))
+        jobs.append(("g9_drop_bl6_lap_s1l0", gen_dropout,
+                     dict(cfg=C.bl6_laplace(1, 0), frames=[9, 7], wseed=72, flavor="trained", aux_seed=12, drop_seed=82,
+                          p=0.5, big=True)))
+        jobs.append(("g9_drop_ref6_smx", gen_dropout,
+                     dict(cfg=C.ref6_softmax(), frames=[9, 7], wseed=73, flavor="xavier", aux_seed=12, drop_seed=83,
+                          p=0.5, big=True)))
     for name, fn, kw in jobs:
         if args.only and args.only not in name:
             continue

@@ -32,10 +32,12 @@ class NetDesc(ctypes.Structure):
 class DecodeIO(ctypes.Structure):
     """mirror of `swn_decode_io` (include/swn_hip.h): inputs of the sampling loop."""
     _fields_ = [("noise_dev", c_void_p), ("forced_dev", c_void_p), ("seed_dev", c_void_p), ("noise_out_dev", c_void_p),
-                ("rng_seed", ctypes.c_uint64), ("rng_utt0", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+                ("rng_seed", ctypes.c_uint64), ("rng_utt0", ctypes.c_uint32), ("reserved", ctypes.c_uint32),
+                ("rng_utt_ids_dev", c_void_p)]
 
 
-ABI_VERSION = 2
+ABI_VERSION = 3
+PRECISION_FP32, PRECISION_BF16 = 0, 1          # SWN_PRECISION_* (include/swn_hip.h)
 
 
 def desc_from_cfg(cfg: NetConfig) -> NetDesc:
@@ -78,10 +80,10 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p]),
     "swn_backward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_backward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                             c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                             c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "swn_forward_drop_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward_drop": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
-                                 c_void_p, c_void_p, c_void_p, c_void_p]),
+                                 c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "swn_unfold_grads_device": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "swn_forward_bf16_keep_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward_bf16_keep": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
@@ -93,11 +95,9 @@ SIGNATURES = {
                           c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "swn_backward_drop_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_backward_drop": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
-                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+                                  c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "swn_bf16_train_forward_supported": (c_int, [POINTER(NetDesc)]),
-    "swn_bf16_work_to_f32": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
-    "swn_train_set_precision": (c_int, [c_int]),
-    "swn_train_get_precision": (c_int, []),
+    "swn_bf16_work_to_f32": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "swn_laplace_head_backward": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                           c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "swn_laplace_head": (c_int, [POINTER(NetDesc), c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -155,6 +155,15 @@ def lib() -> ctypes.CDLL:
             return _lib
         if not os.path.exists(LIB_PATH):
             build()
+        elif is_stale():
+            # a binary that was not built from the sources in the tree: rebuild where a compiler exists, else say so
+            import shutil
+            import warnings
+            if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
+                build()
+            else:
+                warnings.warn(f"{LIB_PATH} was not built from the sources in this tree (source hash differs) and no hipcc "
+                              "is available to rebuild it", RuntimeWarning)
         # torch ships its own libamdhip64; it must be in the process BEFORE our library so that both
         # resolve to ONE HIP runtime (device pointers and streams come from torch).  Loading ours
         # first binds /opt/rocm's copy, which then reports "no ROCm-capable device".

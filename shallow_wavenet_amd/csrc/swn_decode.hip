@@ -361,7 +361,7 @@ extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const floa
     if ((long)n_steps * a.g.seg > (long)n_frames * a.g.U) return SWN_E_BADARG;   // conditioning too short
     SwnNoise nz;
     nz.ptr = io->noise_dev; nz.dump = io->noise_out_dev;
-    nz.key0 = (uint32_t)(io->rng_seed & 0xffffffffu); nz.key1 = (uint32_t)(io->rng_seed >> 32); nz.utt0 = io->rng_utt0;
+    nz.key0 = (uint32_t)(io->rng_seed & 0xffffffffu); nz.key1 = (uint32_t)(io->rng_seed >> 32); nz.utt0 = io->rng_utt0; nz.ids = io->rng_utt_ids_dev;
     const void* forced = io->forced_dev;
     const void* seed = io->seed_dev;
     hipStream_t st = (hipStream_t)stream_;

@@ -165,6 +165,20 @@ static inline __host__ int swn_tensor_count(const SwnGeom* g) {
     return 2 + 2 * g->auxl + 2 + (g->conv2d ? 2 : 0) + (g->wav ? 2 : 0) + 2 + 6 * g->L + 4;
 }
 
+// Arithmetic mode of the training call in progress ON THIS THREAD: every training entry point takes it as an argument
+// (SWN_PRECISION_FP32 | SWN_PRECISION_BF16) and holds it in a SwnModeScope for the duration of the call, so the launch
+// helpers below it need no extra parameter and nothing outlives the call (the C ABI has no process-wide state).
+int  swn_call_mode();                 // csrc/swn_train.hip
+void swn_call_mode_set(int mode);
+struct SwnModeScope {
+    int prev;
+    explicit SwnModeScope(int mode) : prev(swn_call_mode()) { swn_call_mode_set(mode); }
+    ~SwnModeScope() { swn_call_mode_set(prev); }
+    SwnModeScope(const SwnModeScope&) = delete;
+    SwnModeScope& operator=(const SwnModeScope&) = delete;
+};
+static inline bool swn_precision_ok(int mode) { return mode == SWN_PRECISION_FP32 || mode == SWN_PRECISION_BF16; }
+
 // thread-local text of the last HIP failure seen by an entry point (swn_last_error_detail())
 extern "C" void swn_set_error_detail(const char* where, const char* what);
 #ifdef HIP_INCLUDE_HIP_HIP_RUNTIME_H

@@ -30,7 +30,7 @@ __device__ __forceinline__ void swn_mma_64x64x16(const float (*As)[SWN_MMA_PITCH
 __device__ __forceinline__ int swn_mma_row(int lane, int mt, int i) { return 16 * mt + 4 * (lane >> 4) + i; }
 __device__ __forceinline__ int swn_mma_col(int lane, int w) { return 16 * w + (lane & 15); }
 
-// ---- bf16-operand variant (mixed-precision training mode, swn_train_set_precision(1)): the same 64 x 64 tile and
+// ---- bf16-operand variant (mixed-precision training mode, precision = SWN_PRECISION_BF16): the same 64 x 64 tile and
 // accumulator layout, k-tile of 32 with v_mfma_f32_16x16x32_bf16 (16x the rate of the exact fp32 instruction), fp32
 // accumulation.  LDS holds the operands row-major in k as packed bf16 pairs: As[row][k/2], Bs[col][k/2], 80-byte rows
 // (conflict-free 16-byte fragment reads).

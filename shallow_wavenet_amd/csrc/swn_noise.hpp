@@ -4,7 +4,7 @@
 // uploaded by the host.
 //
 // Generator: Philox4x32-10 (Salmon et al., SC'11), key = the 64-bit seed, counter = (global utterance index, step,
-// word group, stream tag).  Every draw is a pure function of (seed, utterance, step, element): results do not depend on
+// word group, stream tag); the index is rng_utt0 + b or the caller's per-utterance list (swn_decode_io.rng_utt_ids_dev).  Every draw is a pure function of (seed, utterance, step, element): results do not depend on
 // batch composition, on the decode kernel variant, or on how utterances are sharded over GPUs.
 //   Laplace: e = -0.4999 + 0.9999 * u24,  u24 = (bits >> 8) * 2^-24 in [0, 1)      (uniform_(-0.4999, 0.5))
 //   softmax: q = -log(u),                 u   = ((bits >> 9) + 0.5) * 2^-23 in (0, 1)   (Exp(1) of multinomial's n=1 path)
@@ -16,8 +16,11 @@ struct SwnNoise {
     const float* ptr;          // host-drawn stream (B, n_steps, width) or nullptr -> generate in the kernel
     float* dump;               // optional: every value used is also written here, same layout (tests replay it in the oracle)
     uint32_t key0, key1;       // 64-bit seed
-    uint32_t utt0;             // global index of utterance 0 of this launch
+    uint32_t utt0;             // global index of utterance 0 of this launch (utterance b = utt0 + b) ...
+    const uint32_t* ids;       // ... or, when not null, the global index of every utterance of the launch (B values)
 };
+
+__device__ __forceinline__ uint32_t swn_utt_id(const SwnNoise& n, uint32_t utt) { return n.ids ? n.ids[utt] : n.utt0 + utt; }
 
 __device__ __forceinline__ uint4 swn_philox4x32_10(uint4 c, uint2 k) {
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
@@ -32,7 +35,7 @@ __device__ __forceinline__ uint4 swn_philox4x32_10(uint4 c, uint2 k) {
 }
 
 __device__ __forceinline__ uint32_t swn_rng_word(const SwnNoise& n, uint32_t utt, uint32_t step, uint32_t elem, uint32_t tag) {
-    const uint4 r = swn_philox4x32_10(make_uint4(n.utt0 + utt, step, elem >> 2, tag), make_uint2(n.key0, n.key1));
+    const uint4 r = swn_philox4x32_10(make_uint4(swn_utt_id(n, utt), step, elem >> 2, tag), make_uint2(n.key0, n.key1));
     const uint32_t s = elem & 3u;
     return s == 0 ? r.x : (s == 1 ? r.y : (s == 2 ? r.z : r.w));
 }
@@ -73,7 +76,7 @@ __device__ __forceinline__ float4 swn_noise_exp1x4(const SwnNoise& n, int b, int
     if (n.ptr) {
         q = *reinterpret_cast<const float4*>(n.ptr + at);
     } else {
-        const uint4 r = swn_philox4x32_10(make_uint4(n.utt0 + (uint32_t)b, (uint32_t)step, (uint32_t)g, 0x45585031u),
+        const uint4 r = swn_philox4x32_10(make_uint4(swn_utt_id(n, (uint32_t)b), (uint32_t)step, (uint32_t)g, 0x45585031u),
                                           make_uint2(n.key0, n.key1));
         q.x = -logf(((float)(r.x >> 9) + 0.5f) * 1.1920928955078125e-7f);
         q.y = -logf(((float)(r.y >> 9) + 0.5f) * 1.1920928955078125e-7f);

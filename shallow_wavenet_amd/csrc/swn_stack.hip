@@ -357,7 +357,7 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL(tf_input_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, a);
     }
-    if (drop && swn_train_get_precision() == 1 && swn_drop_bf16_forward(&g)) {
+    if (drop && swn_call_mode() == SWN_PRECISION_BF16 && swn_drop_bf16_forward(&g)) {
         // mixed-precision mode: bf16-operand GEMM + element-wise gate per layer; after gx in the work buffer: the gate
         // pre-activations of every layer (B, 2H, Tp) x L - kept, the backward of the same mode reads them instead of
         // recomputing - | masked input of one layer (B, H, Tp)
@@ -375,7 +375,7 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
     const size_t hstride = (size_t)(g.L + 1) * g.H * Tp;
     // skip: one GEMM over the L concatenated (undropped) hidden states (requires Hp == H, i.e. H % 4 == 0)
     if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
-    if (drop && swn_train_get_precision() == 1 && !hs && swn_drop_bf16_forward(&g)) {
+    if (drop && swn_call_mode() == SWN_PRECISION_BF16 && !hs && swn_drop_bf16_forward(&g)) {
         // mixed-precision mode: the two wide 1x1 layers as bf16-operand time GEMMs with bias + relu epilogues (0.5 ms each as
         // exact-fp32 gemm_wx at the run.sh geometry); out_2 (<= 16 rows) stays below
         rc = swn_train_head_acts(g, packed, work, batch, Tp, st);
@@ -415,8 +415,9 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
 
 extern "C" int swn_forward_drop(const swn_net_desc* d, const float* packed, const float* fe_work, const void* audio,
                                 int batch, int n_frames, const float* drop_x, const float* const* drop_h,
-                                float* work, float* out, float* hs, void* stream_) {
-    if (!drop_x) return SWN_E_BADARG;
+                                float* work, float* out, float* hs, int precision, void* stream_) {
+    if (!drop_x || !swn_precision_ok(precision)) return SWN_E_BADARG;
+    SwnModeScope mode(precision);
     return forward_impl(d, packed, nullptr, fe_work, audio, batch, n_frames, drop_x, drop_h, work, out, hs, stream_,
                         "swn_forward_drop");
 }

@@ -808,7 +808,7 @@ extern "C" int swn_forward_bf16_keep(const swn_net_desc* d, const float* packed,
 // that swn_backward can follow a bf16 forward (mixed-precision training).  GEMM-stack class: hidden states, relu(skip)
 // and relu(out_1) are all in memory.  BL6 class: the fused head keeps the two activations on chip, so the hidden
 // states are expanded and the two 1x1 products are redone by the training contraction kernel, in the arithmetic mode
-// of swn_train_set_precision (packed_dev needed only there).
+// given by `precision` (packed_dev needed only there).
 extern "C" int swn_bf16_train_forward_supported(const swn_net_desc* d) {
     SwnGeom g;
     if (bf_geom(d, &g) == SWN_OK) return 1;
@@ -816,7 +816,9 @@ extern "C" int swn_bf16_train_forward_supported(const swn_net_desc* d) {
 }
 
 extern "C" int swn_bf16_work_to_f32(const swn_net_desc* d, const float* packed, const void* work_bf16, int batch, int n_frames,
-                                    float* fwd_work, void* stream_) {
+                                    float* fwd_work, int precision, void* stream_) {
+    if (!swn_precision_ok(precision)) return SWN_E_BADARG;
+    SwnModeScope mode(precision);
     SwnGeom g;
     const bool small = bf_geom(d, &g) == SWN_OK;
     if (!small) { const int rc = swn_bf16g_geom(d, &g); if (rc < 0) return rc; }

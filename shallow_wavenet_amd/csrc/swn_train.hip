@@ -12,7 +12,7 @@
 // the Laplace head.  Hidden states h_0..h_L saved by the forward are reused; the gate pre-activations
 // are recomputed (one extra conv GEMM per layer) instead of being stored.
 //
-// Mixed-precision mode (swn_train_set_precision(1)): the same chain with bf16 operands on the matrix cores -
+// Mixed-precision mode (precision = SWN_PRECISION_BF16): the same chain with bf16 operands on the matrix cores -
 //   time_gemm_bf16t_kernel / reduce_gemm_bf16s_kernel   128 x 128 tiles, fp32 operands rounded on the way into LDS
 //   time_gemm_b16_kernel, reduce_gemm_bf16s_kernel<true, true>   the layer GEMMs of the GEMM-stack geometries with BOTH
 //       operands read as bf16: gate_bwd_kernel leaves da and the layer input as bf16 rows (two copies each, the second moved
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void time_gemm_kernel(const TimeGemm g) {
     tg_epilogue<16>(g, b, mrow, t, v);
 }
 
-// bf16-operand twin of time_gemm_kernel (swn_train_set_precision(1)): same operands in HBM (fp32), rounded to bf16 on
+// bf16-operand twin of time_gemm_kernel (precision = SWN_PRECISION_BF16): same operands in HBM (fp32), rounded to bf16 on
 // their way into LDS, k-tiles of 32, fp32 accumulators and the same epilogue.  A thread stages k-PAIRS (one packed
 // LDS word each); the (tap, c) of every k index advances without divisions.
 template <bool XMUL>
@@ -1234,12 +1234,13 @@ __global__ __launch_bounds__(256) void laplace_head_bwd_kernel(const float* __re
 
 size_t r64(size_t x) { return (x + 63) & ~(size_t)63; }
 
-// process-wide arithmetic mode of the two contraction kernels (swn_train_set_precision)
-std::atomic<int> g_train_bf16{0};
+// arithmetic mode of the training call in progress on this thread (SwnModeScope, csrc/swn_geom.hpp)
+thread_local int t_call_mode = SWN_PRECISION_FP32;
+inline bool mode_bf16() { return t_call_mode == SWN_PRECISION_BF16; }
 
 void launch_time(const TimeGemm& g, int B, hipStream_t st) {
     const dim3 grid((g.T + 63) / 64, (g.M + 63) / 64, B);
-    if (g_train_bf16.load(std::memory_order_relaxed)) {
+    if (mode_bf16()) {
         if (!g.xmul && g.x_st == 1 && g.KC % 32 == 0) {
             TimeGemm h = g;
             h.nb = B;
@@ -1276,7 +1277,7 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
     g.TS = 512;
     const int nseg = (g.T + g.TS - 1) / g.TS;
     const dim3 grid((g.M + 63) / 64, (g.taps * g.KC + 63) / 64, B * nseg);
-    if (g_train_bf16.load(std::memory_order_relaxed)) {
+    if (mode_bf16()) {
         if (!g.qmul && g.p_st == 1 && g.q_st == 1 && g.T >= 256) {
             // 128 x 128 tiles; time segments sized for a target number of workgroups
             const int mt = (g.M + 127) / 128, nt = (g.taps * g.KC + 127) / 128;
@@ -1312,12 +1313,8 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int swn_train_set_precision(int mode) {
-    if (mode != 0 && mode != 1) return SWN_E_BADARG;
-    g_train_bf16.store(mode, std::memory_order_relaxed);
-    return SWN_OK;
-}
-extern "C" int swn_train_get_precision(void) { return g_train_bf16.load(std::memory_order_relaxed); }
+int  swn_call_mode() { return t_call_mode; }
+void swn_call_mode_set(int mode) { t_call_mode = mode; }
 
 extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int n_frames) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
@@ -1415,7 +1412,7 @@ __global__ __launch_bounds__(256) void xm_bwd_kernel(const float* __restrict__ d
 }  // namespace
 
 // relu(skip) and relu(out_1) from fp32 hidden states already in `work` (layout of swn_forward_work_floats) through the
-// contraction kernels of this file, i.e. in the arithmetic mode of swn_train_set_precision: the tail of the training
+// contraction kernels of this file, i.e. in the arithmetic mode of the call (SwnModeScope): the tail of the training
 // forward when the hidden states come from the BL6-class bf16 layer kernels (swn_bf16_work_to_f32).
 int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int B, long Tp, hipStream_t st) {
     if (g.Hp != g.H) return SWN_E_UNSUPPORTED;
@@ -1578,7 +1575,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const float* gx = xm + r64((size_t)B * swn_a0x(&g) * Tx);
     // dropout mode in the mixed-precision mode: swn_forward_drop of the same mode kept every layer's gate pre-activations
     // behind gx (the arithmetic mode must not change between a forward and its backward)
-    const float* saved_a = (drop && g_train_bf16.load(std::memory_order_relaxed) == 1 && !hs_opt && swn_drop_bf16_forward(&g))
+    const float* saved_a = (drop && mode_bf16() && !hs_opt && swn_drop_bf16_forward(&g))
                                ? gx + r64((size_t)B * L * H2 * Tp) : a_keep;   // a_keep: swn_forward_bf16_keep's buffer (same slots)
     float* dxm = dfe + r64(fe_tot * B * n_frames);
     float* hmask = dxm + r64((size_t)B * g.A0 * Tx);               // dropout mode only: masked input of a layer (B, H, Tp)
@@ -1593,7 +1590,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     // mixed-precision chain: gate_bwd also leaves da as bf16 rows (pitch = Tp rounded up to 32) for the layer weight gradients
     const long da16_pitch = (Tp + 2 + 31) & ~31L, da16_odd = (long)B * H2 * da16_pitch;
     unsigned short* da16 = nullptr;
-    if (!hs_bf16 && g_train_bf16.load(std::memory_order_relaxed) == 1)
+    if (!hs_bf16 && mode_bf16())
         da16 = reinterpret_cast<unsigned short*>(drop ? hmask + r64((size_t)B * H * Tp) : dxm + (size_t)SWN_WUP_COPIES * 256);
     ga.da16 = da16; ga.da16_pitch = da16_pitch; ga.da16_odd = da16_odd;
     // ... and the layer's (masked) input, for the weight gradient's Q operand; second copy within 32-bit reach as for da
@@ -1780,7 +1777,10 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
 
 extern "C" int swn_backward(const swn_net_desc* d, const float* packed, const float* aux, const float* cond,
                             const float* fe_work, const void* audio, const float* fwd_work, const float* hs_opt,
-                            const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
+                            const float* grad_out, int batch, int n_frames, float* work, float* gpacked, int precision,
+                            void* stream_) {
+    if (!swn_precision_ok(precision)) return SWN_E_BADARG;
+    SwnModeScope mode(precision);
     return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, hs_opt, nullptr, nullptr, grad_out, batch, n_frames,
                          work, gpacked, stream_, "swn_backward");
 }
@@ -1800,6 +1800,7 @@ extern "C" int swn_backward_bf16(const swn_net_desc* d, const float* packed, con
                                  const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
     if (!work_bf16) return SWN_E_BADARG;
     if (swn_backward_bf16_work_floats(d, batch, n_frames) == 0) return SWN_E_UNSUPPORTED;
+    SwnModeScope mode(SWN_PRECISION_BF16);                 // this path exists in the mixed-precision arithmetic only
     return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, nullptr, nullptr, nullptr, grad_out, batch, n_frames,
                          work, gpacked, stream_, "swn_backward_bf16", work_bf16);
 }
@@ -1810,6 +1811,7 @@ extern "C" int swn_backward_keep(const swn_net_desc* d, const float* packed, con
                                  const float* fe_work, const void* audio, const float* fwd_work, const float* a_keep,
                                  const float* grad_out, int batch, int n_frames, float* work, float* gpacked, void* stream_) {
     if (!a_keep) return SWN_E_BADARG;
+    SwnModeScope mode(SWN_PRECISION_BF16);                 // follows swn_forward_bf16_keep: mixed precision by construction
     return backward_impl(d, packed, aux, cond, fe_work, audio, fwd_work, nullptr, nullptr, nullptr, grad_out, batch, n_frames,
                          work, gpacked, stream_, "swn_backward_keep", nullptr, a_keep);
 }
@@ -1826,8 +1828,9 @@ extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch
 extern "C" int swn_backward_drop(const swn_net_desc* d, const float* packed, const float* aux, const float* fe_work,
                                  const void* audio, const float* fwd_work, const float* hs_opt, const float* drop_x,
                                  const float* const* drop_h, const float* grad_out, int batch, int n_frames, float* work,
-                                 float* gpacked, void* stream_) {
-    if (!drop_x) return SWN_E_BADARG;
+                                 float* gpacked, int precision, void* stream_) {
+    if (!drop_x || !swn_precision_ok(precision)) return SWN_E_BADARG;
+    SwnModeScope mode(precision);
     return backward_impl(d, packed, aux, nullptr, fe_work, audio, fwd_work, hs_opt, drop_x, drop_h, grad_out, batch, n_frames,
                          work, gpacked, stream_, "swn_backward_drop");
 }

@@ -6,9 +6,15 @@ batching (:77-84), zero `pad_list` in raw feature space (:30-48), seed waveform 
 class 128, all utterances of a batch run max(n_samples) steps, 16-bit PCM WAV output, the two
 summary log lines (:256-259), contiguous `np.array_split` sharding over GPUs (:200-201).
 
-Different on purpose: one process per GPU under `torchrun` (RANK/WORLD_SIZE) instead of forked
-children, and rank 0 packs the checkpoint once and broadcasts the flat parameter buffer over RCCL
-instead of every process reading the checkpoint file.  Without torchrun, `--n_gpus 1` runs in-process.
+`--n_gpus N` as run.sh:675-684 passes it: the parent (which never touches a GPU) starts one child process per
+shard (spawn context, rank r on GPU r of `--GPU_device_str` - decode_cswnv...py:261-274) and returns non-zero if
+any child does.  Different on purpose: rank 0 packs the checkpoint once and broadcasts the flat parameter buffer
+over RCCL instead of every process reading the checkpoint file; the same ranks can be started by `torchrun`
+(RANK/WORLD_SIZE in the environment).  `--n_gpus 1` runs in-process.
+
+Device-drawn sampling noise (`--noise_source device`, the softmax default) is keyed by ONE value drawn after
+`torch.manual_seed(--seed)` and by each utterance's position in the unsorted `--feats` list, so an utterance draws
+the same stream whatever `--n_gpus` and wherever the length sort puts it.
 
 Feature files: `<utt>.npy` (T x n_aux float arrays) always; `<utt>.h5` with the dataset named by
 `config.string_path` when h5py is importable (it is not in the build image).
@@ -46,13 +52,20 @@ def feature_frames(path: str, string_path: str) -> int:
     return int(featio.dataset_shape(featio.resolve(path), string_path)[0])
 
 
-def list_features(feats: str) -> List[str]:
-    """directory -> sorted recursive *.h5 / *.npy ; file -> one path per line (utils.py:129-160)."""
+def list_features(feats: str, string_path: str = None) -> List[str]:
+    """directory -> sorted recursive *.h5 (and the .npz / .npy side formats) ; file -> one path per line
+    (utils.py:129-160).  An utterance present in several formats is listed once (.h5 before .npz before .npy); with
+    `string_path` given, container files that do not hold that dataset (a `stats.npz` written by calc_stats next to
+    the features) are not utterances and are skipped."""
     if os.path.isdir(feats):
-        out = []
-        for ext in ("*.h5", "*.npz", "*.npy"):
-            out += glob.glob(os.path.join(feats, "**", ext), recursive=True)
-        return sorted(out)
+        best = {}
+        for rank, ext in enumerate((".h5", ".npz", ".npy")):
+            for f in glob.glob(os.path.join(feats, "**", "*" + ext), recursive=True):
+                best.setdefault(f[: -len(ext)], (rank, f))
+        out = sorted(f for _, f in best.values())
+        if string_path is not None:
+            out = [f for f in out if f.endswith(".npy") or featio.check_dataset(f, string_path)]
+        return out
     if os.path.isfile(feats):
         with open(feats) as f:
             return [ln.strip() for ln in f if ln.strip()]
@@ -79,13 +92,18 @@ def plan_batches(feat_list: Sequence[str], frames: Sequence[int], batch_size: in
     return [a.tolist() for a in np.array_split(ordered, n_batch)]
 
 
-def decode_batches(feat_list: Sequence[str], batch_size: int, string_path: str, upsampling_factor: int
+def decode_batches(feat_list: Sequence[str], batch_size: int, string_path: str, upsampling_factor: int,
+                   global_index: Sequence[int] = None
                    ) -> Iterator[Tuple[List[str], np.ndarray, List[int]]]:
+    """yields (utterance ids, padded features, n_samples) per batch; with `global_index` (position of every file of
+    `feat_list` in the unsorted full list) a fourth value: those positions for the batch's utterances."""
     frames = [feature_frames(f, string_path) for f in feat_list]
+    where = {f: i for i, f in enumerate(feat_list)}
     for batch in plan_batches(feat_list, frames, batch_size):
         hs = [read_feature(f, string_path) for f in batch]
         ids = [os.path.splitext(os.path.basename(f))[0] for f in batch]
-        yield ids, pad_list(hs), [h.shape[0] * upsampling_factor for h in hs]
+        item = (ids, pad_list(hs), [h.shape[0] * upsampling_factor for h in hs])
+        yield item if global_index is None else item + ([int(global_index[where[f]]) for f in batch],)
 
 
 def write_wav_pcm16(path: str, samples: np.ndarray, fs: int) -> None:
@@ -123,8 +141,11 @@ def build_model(kind: str, config):
         wav_conv_flag=config.wav_conv_flag, upsampling_factor=config.upsampling_factor)
 
 
-def gpu_decode(kind: str, args, config, feat_list: Sequence[str], device, packed_src_rank: int = 0):
-    """decode one shard on one GPU (decode_cswnv...py:204-259)."""
+def gpu_decode(kind: str, args, config, feat_list: Sequence[str], device, packed_src_rank: int = 0,
+               global_index: Sequence[int] = None, rng_key: int = None):
+    """decode one shard on one GPU (decode_cswnv...py:204-259).  global_index / rng_key: every utterance's position in
+    the unsorted full list and the run's one generator key - device-drawn noise then depends on neither batching nor
+    sharding (module attributes noise_utterance_ids / noise_rng_seed)."""
     with torch.no_grad():
         model = build_model(kind, config)
         rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
@@ -138,11 +159,15 @@ def gpu_decode(kind: str, args, config, feat_list: Sequence[str], device, packed
         model.to(device)
         model.eval()
         model.noise_source = getattr(args, "noise_source", None)
+        model.noise_rng_seed = rng_key
+        if global_index is None:
+            global_index = list(range(len(feat_list)))
         model.set_packed_engine(HipNet(cfg, D.broadcast_packed(cfg, packed, device, src=packed_src_rank), device))
         string_path = getattr(config, "string_path", "/feat_org_lf0")
         t_total, n_max, n_tot = 0.0, 0, 0
-        for ids, batch_h, n_samples_list in decode_batches(feat_list, args.batch_size, string_path,
-                                                           config.upsampling_factor):
+        for ids, batch_h, n_samples_list, utt_index in decode_batches(feat_list, args.batch_size, string_path,
+                                                                      config.upsampling_factor, global_index):
+            model.noise_utterance_ids = utt_index
             aux = torch.FloatTensor(batch_h).transpose(1, 2).to(device)
             if kind == "laplace":
                 seed = torch.zeros(len(ids), model.seg, device=device)
@@ -186,11 +211,79 @@ def make_parser() -> argparse.ArgumentParser:
                    help="not a reference flag: where the sampling noise is drawn - host = the torch CPU generator in "
                         "the reference's order (reproduces the reference's CPU decode), device = inside the kernels; "
                         "default: the model's own default (Laplace host, softmax device)")
+    p.add_argument("--plan_only", action="store_true",
+                   help="not a reference flag: stop after listing, sharding and the parameter broadcast and write "
+                        "<outdir>/decode.<rank>.plan.json (needs no GPU: what the CPU tests of the fan-out drive)")
     return p
+
+
+def _write_plan(kind: str, args, config, rank: int, world: int, shard, index, rng_key: int) -> int:
+    """--plan_only: everything a rank does before its first kernel - checkpoint -> packed buffer on rank 0, the one
+    broadcast, the batches of its shard with their global utterance indices - written as JSON, no GPU involved."""
+    cfg = build_model(kind, config)._cfg
+    packed = None
+    if rank == 0:
+        model = build_model(kind, config)
+        model.load_state_dict(artefacts.load_checkpoint(args.checkpoint)["model"])
+        packed = pack_state_dict(cfg, model.state_dict())
+    buf = D.broadcast_packed(cfg, packed, "cpu")
+    string_path = getattr(config, "string_path", "/feat_org_lf0")
+    batches = [{"ids": ids, "n_samples": n, "utt_index": ui}
+               for ids, _, n, ui in decode_batches(shard, args.batch_size, string_path, config.upsampling_factor, index)]
+    with open(os.path.join(args.outdir, f"decode.{rank}.plan.json"), "w") as f:
+        json.dump({"rank": rank, "world": world, "shard": list(shard), "index": index, "rng_key": int(rng_key),
+                   "packed_numel": int(buf.numel()), "packed_sum": float(buf.double().sum()), "batches": batches}, f)
+    D.barrier()
+    if world > 1:
+        torch.distributed.destroy_process_group()
+    return 0
+
+
+def _rank_main(kind: str, argv, rank: int, world: int, port: int, visible: str) -> None:
+    """entry of one spawned rank: the torchrun environment contract, then `main` (never returns: exits with its code)."""
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if visible:
+        # the reference exports CUDA_VISIBLE_DEVICES = GPU_device_str and uses GPU r of that list (decode_cswnv...py:150-154,263)
+        os.environ["HIP_VISIBLE_DEVICES"] = visible
+    sys.exit(main(kind, argv))
+
+
+def fan_out(kind: str, argv, n_gpus: int, visible: str = None) -> int:
+    """`--n_gpus N` without a launcher (run.sh:675-684): one spawned process per shard, rendezvous on 127.0.0.1, wait for
+    all (decode_cswnv...py:261-274).  The parent makes no GPU call.  -> 0, or 1 if any rank failed (the others are ended:
+    they would wait in the broadcast / barrier for ever)."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    procs = [ctx.Process(target=_rank_main, args=(kind, list(argv) if argv is not None else sys.argv[1:], r, n_gpus, port,
+                                                  visible)) for r in range(n_gpus)]
+    for p in procs:
+        p.start()
+    failed = False
+    live = list(procs)
+    while live:
+        for p in list(live):
+            p.join(timeout=0.1)
+            if p.exitcode is None:
+                continue
+            live.remove(p)
+            if p.exitcode != 0 and not failed:
+                failed = True
+                for q in live:
+                    q.terminate()
+    return 1 if failed else 0
 
 
 def main(kind: str, argv=None) -> int:
     args = make_parser().parse_args(argv)
+    if "WORLD_SIZE" not in os.environ and args.n_gpus > 1:
+        return fan_out(kind, argv, args.n_gpus, args.GPU_device_str)        # before anything below can touch a GPU
     rank, world, local = D.init_from_env()
     os.makedirs(args.outdir, exist_ok=True)
     level = logging.INFO if args.verbose > 0 else logging.WARN
@@ -204,27 +297,33 @@ def main(kind: str, argv=None) -> int:
     config = load_config(args.config)
     logging.info(config)
     try:
-        feat_list = list_features(args.feats)
+        feat_list = list_features(args.feats, getattr(config, "string_path", "/feat_org_lf0"))
     except FileNotFoundError:
         logging.error("--feats should be directory or list.")
         return 1
     if world > 1 and args.n_gpus != world:
-        logging.warning("--n_gpus %d ignored: running under torchrun with %d ranks", args.n_gpus, world)
-    if world == 1 and args.n_gpus > 1:
-        logging.error("multi-GPU decode runs one process per GPU: launch with "
-                      "python -m torch.distributed.run --nproc-per-node %d ..." % args.n_gpus)
-        return 1
-    shard = D.shard_utterances(feat_list, world)[rank]
+        logging.warning("--n_gpus %d ignored: running under a launcher with %d ranks", args.n_gpus, world)
+    # the one key of the in-kernel noise generator, identical on every rank; from a generator of its own so that the
+    # host stream (module init draws, host-drawn noise) stays what the reference's script would draw after manual_seed
+    from . import noise as _noise
+    rng_key = _noise.draw_rng_seed(torch.Generator().manual_seed(args.seed))
+    index = [int(i) for i in D.shard_utterances(range(len(feat_list)), world)[rank]]   # np.array_split, decode_cswnv...py:200-201
+    shard = [feat_list[i] for i in index]
+    if args.plan_only:
+        return _write_plan(kind, args, config, rank, world, shard, index, rng_key)
     if not torch.cuda.is_available():
         logging.error("no HIP device: the MI355X build has no CPU path")
         return 1
-    if args.GPU_device_str is not None and world == 1:
+    n_dev = torch.cuda.device_count()
+    if world == 1 and args.GPU_device_str is not None:
         local = int(args.GPU_device_str.split(",")[0])
     elif world == 1:
         local = args.GPU_device
+    elif local >= n_dev:
+        local = local % n_dev            # more ranks than visible GPUs (a one-GPU test box): share; the broadcast then runs over gloo
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
-    gpu_decode(kind, args, config, shard, device)
+    gpu_decode(kind, args, config, shard, device, global_index=index, rng_key=rng_key)
     D.barrier(device)
     if world > 1:
         torch.distributed.destroy_process_group()

@@ -29,7 +29,8 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # RCCL needs one GPU per rank; more ranks than visible GPUs (rehearsals on a one-GPU box) or no GPU: gloo
+            backend = "nccl" if torch.cuda.is_available() and torch.cuda.device_count() >= world else "gloo"
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend == "nccl":
@@ -58,20 +59,25 @@ def broadcast_packed(cfg: NetConfig, packed: Optional[torch.Tensor], device, src
         if packed is None:
             raise RuntimeError("single process: the packed buffer must be supplied")
         return packed.to(device)
+    via = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(device)   # gloo moves host memory
     if dist.get_rank() == src:
         if packed is None or packed.numel() != n:
             raise RuntimeError("source rank must supply the packed buffer")
-        buf = packed.to(device).contiguous()
+        buf = packed.to(via).contiguous()
     else:
-        buf = torch.empty(n, dtype=torch.float32, device=device)
+        buf = torch.empty(n, dtype=torch.float32, device=via)
     dist.broadcast(buf, src=src)
-    return buf
+    return buf.to(device)
+
+
+def _reduce_device(device):
+    return torch.device("cpu") if dist.get_backend() == "gloo" else device
 
 
 def max_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -79,14 +85,14 @@ def max_over_ranks(value: float, device) -> float:
 def sum_over_ranks(value: float, device) -> float:
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device=_reduce_device(device))
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return float(t.item())
 
 
 def barrier(device=None) -> None:
     if dist.is_initialized() and dist.get_world_size() > 1:
-        if device is not None and torch.device(device).type == "cuda":
+        if device is not None and torch.device(device).type == "cuda" and dist.get_backend() != "gloo":
             dist.barrier(device_ids=[torch.device(device).index])
         else:
             dist.barrier()

@@ -160,8 +160,12 @@ class DSWNV(EngineMixin, nn.Module):
                 noise = _noise.softmax_exponential(self._cfg, n_steps, B)     # Exp(1) draws of multinomial(n=1)
                 out, _ = net.decode(aux, n_steps, noise, seed=seed)
             else:
-                out, _ = net.decode(aux, n_steps, None, seed=seed, rng_seed=_noise.draw_rng_seed(),
-                                    rng_utt0=int(getattr(self, "noise_utterance_offset", 0)))
+                # one fresh key per call unless the caller pinned one for the run (decode_driver: so that an utterance's
+                # stream depends only on (key, its global index), not on batching or on the number of GPUs)
+                key = getattr(self, "noise_rng_seed", None)
+                out, _ = net.decode(aux, n_steps, None, seed=seed, rng_seed=_noise.draw_rng_seed() if key is None else int(key),
+                                    rng_utt0=int(getattr(self, "noise_utterance_offset", 0)),
+                                    utt_ids=getattr(self, "noise_utterance_ids", None))
             samples = out.cpu().numpy().astype(np.int64)
             log_decode_speed(1, n_steps, len(n_samples_list), time.time() - start)
         return [samples[b, :n] for b, n in zip(range(B), n_samples_list)]

@@ -14,12 +14,12 @@ implementations are registered so the ops trace under `torch.compile` / `FakeTen
     torch.ops.swn.pack_params(tensors, desc)                       -> packed
     torch.ops.swn.frontend(packed, aux, desc)                      -> (cond, work)
     torch.ops.swn.decode(packed, cond, noise?, forced?, seed?, desc, n_steps, variant, rng_seed, rng_utt0,
-                         want_heads, want_noise)                   -> (out, heads, noise_used)
+                         want_heads, want_noise, utt_ids?)         -> (out, heads, noise_used)
     torch.ops.swn.stack_forward(packed, cond, audio, desc, want_hidden) -> (raw, work, hidden)
     torch.ops.swn.stack_forward_bf16(packed, wbf16, cond, audio, desc)  -> (raw, work)
     torch.ops.swn.pack_bf16(packed, desc)                          -> wbf16
     torch.ops.swn.laplace_head(raw, desc, clip)                    -> (mu, b, logb, a, b_clip, logb_clip, below_floor)
-    torch.ops.swn.stack_backward(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc) -> grad_packed
+    torch.ops.swn.stack_backward(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc, precision) -> grad_packed
     torch.ops.swn.laplace_head_backward(raw, gmu?, gb?, glogb?, ga?, gb_clip?, glogb_clip?, desc) -> grad_raw
 """
 from __future__ import annotations
@@ -154,8 +154,10 @@ def _(packed, aux, desc):
 # ------------------------------------------------------------------------------------------ decode
 def decode_impl(packed: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.Tensor], forced: Optional[torch.Tensor],
            seed: Optional[torch.Tensor], desc: List[int], n_steps: int, variant: int, rng_seed: int, rng_utt0: int,
-           want_heads: bool, want_noise: bool) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    """prologue + n_steps generation steps for every utterance (swn_decode).  noise None = drawn in the kernels."""
+           want_heads: bool, want_noise: bool, utt_ids: Optional[torch.Tensor] = None
+           ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """prologue + n_steps generation steps for every utterance (swn_decode).  noise None = drawn in the kernels, utterance
+    b as global utterance utt_ids[b] (int32 (B), values < 2^31) or rng_utt0 + b."""
     L = _lib.lib()
     d = _desc(desc)
     _need_cuda(packed, "the packed parameters")
@@ -176,6 +178,10 @@ def decode_impl(packed: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.
         seed = seed.to(dev, torch.int32 if soft else torch.float32).contiguous()
         if seed.numel() != B * seg:
             raise RuntimeError(f"seed waveform has {seed.numel()} elements, expected {B * seg}")
+    if utt_ids is not None:
+        utt_ids = utt_ids.to(dev, torch.int32).contiguous()
+        if utt_ids.numel() != B:
+            raise RuntimeError(f"utt_ids has {utt_ids.numel()} elements, expected {B}")
     r = ctypes.byref(d)
     state = torch.empty(L.swn_decode_state_floats(r, B), dtype=torch.float32, device=dev)
     out = torch.empty((B, n_steps * seg), dtype=torch.int32 if soft else torch.float32, device=dev)
@@ -183,7 +189,8 @@ def decode_impl(packed: torch.Tensor, cond: torch.Tensor, noise: Optional[torch.
     used = torch.empty((B, n_steps, width) if want_noise else (0,), dtype=torch.float32, device=dev)
     io = _lib.DecodeIO(noise_dev=_ptr(noise), forced_dev=_ptr(forced), seed_dev=_ptr(seed),
                        noise_out_dev=_ptr(used if want_noise else None),
-                       rng_seed=int(rng_seed) & 0xFFFFFFFFFFFFFFFF, rng_utt0=int(rng_utt0) & 0xFFFFFFFF, reserved=0)
+                       rng_seed=int(rng_seed) & 0xFFFFFFFFFFFFFFFF, rng_utt0=int(rng_utt0) & 0xFFFFFFFF, reserved=0,
+                       rng_utt_ids_dev=_ptr(utt_ids))
     with _on(dev):
         _lib.check(L.swn_decode(r, _ptr(packed), _ptr(cond), B, Tf, n_steps, ctypes.byref(io), _ptr(state), _ptr(out),
                                 _ptr(heads if want_heads else None), variant, _stream(dev)), "decode")
@@ -194,7 +201,7 @@ decode = custom_op("swn::decode", mutates_args=())(decode_impl)
 
 
 @decode.register_fake
-def _(packed, cond, noise, forced, seed, desc, n_steps, variant, rng_seed, rng_utt0, want_heads, want_noise):
+def _(packed, cond, noise, forced, seed, desc, n_steps, variant, rng_seed, rng_utt0, want_heads, want_noise, utt_ids=None):
     d = _desc(desc)
     soft, seg, _, _, n_out, _ = _geom(d)
     B = cond.shape[0]
@@ -369,8 +376,10 @@ def _(raw, gmu, gb, glogb, ga, gb_clip, glogb_clip, desc):
 
 # ------------------------------------------------------------------------------------------ backward of the stack
 def stack_backward_impl(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Tensor, fe_work: torch.Tensor,
-                   audio: torch.Tensor, fwd_work: torch.Tensor, grad_raw: torch.Tensor, desc: List[int]) -> torch.Tensor:
-    """gradient of the loss wrt the packed parameter buffer given d loss / d raw (swn_backward)."""
+                   audio: torch.Tensor, fwd_work: torch.Tensor, grad_raw: torch.Tensor, desc: List[int],
+                   precision: int = 0) -> torch.Tensor:
+    """gradient of the loss wrt the packed parameter buffer given d loss / d raw (swn_backward); precision =
+    SWN_PRECISION_FP32 (0, parity) | SWN_PRECISION_BF16 (1, bf16 operands / fp32 accumulation)."""
     Lb = _lib.lib()
     d = _desc(desc)
     dev = packed.device
@@ -381,7 +390,8 @@ def stack_backward_impl(packed: torch.Tensor, aux: torch.Tensor, cond: torch.Ten
     gp = torch.empty_like(packed)
     with _on(dev):
         _lib.check(Lb.swn_backward(r, _ptr(packed), _ptr(aux), _ptr(cond), _ptr(fe_work), _ptr(audio), _ptr(fwd_work),
-                                   _ptr(None), _ptr(grad_raw), B, Tf, _ptr(work), _ptr(gp), _stream(dev)), "backward")
+                                   _ptr(None), _ptr(grad_raw), B, Tf, _ptr(work), _ptr(gp), int(precision), _stream(dev)),
+                   "backward")
     return gp
 
 
@@ -389,7 +399,7 @@ stack_backward = custom_op("swn::stack_backward", mutates_args=())(stack_backwar
 
 
 @stack_backward.register_fake
-def _(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc):
+def _(packed, aux, cond, fe_work, audio, fwd_work, grad_raw, desc, precision=0):
     return torch.empty_like(packed)
 
 

@@ -91,24 +91,34 @@ LAYOUT_FIELDS = ("scale_w", "scale_b", "aux_w0", "aux_w1", "aux_w2", "aux_w3", "
                  "b2", "total", "bxr")
 
 
+_precision = _lib.PRECISION_FP32      # host-side default handed to the training entry points (the C ABI holds no mode)
+
+
+def current_precision() -> int:
+    """SWN_PRECISION_* value a training-mode forward started now would be run in."""
+    return _precision
+
+
 class train_precision:
-    """context manager / setter for the arithmetic of the backward contractions (include/swn_hip.h,
-    swn_train_set_precision): "fp32" = exact fp32 MFMA (parity mode, default), "bf16" = bf16 operands with fp32
-    accumulation.  Process-wide, like torch.backends flags."""
-    MODES = {"fp32": 0, "bf16": 1}
+    """context manager / setter for the arithmetic of the training contractions: "fp32" = exact fp32 MFMA (parity mode,
+    default), "bf16" = bf16 operands with fp32 accumulation.  Python-side sugar only: the C entry points take the mode
+    as an argument (include/swn_hip.h SWN_PRECISION_*); a forward records the mode it ran in and its backward is
+    issued in that same mode whatever is current by then."""
+    MODES = {"fp32": _lib.PRECISION_FP32, "bf16": _lib.PRECISION_BF16}
 
     def __init__(self, mode: str):
+        global _precision
         if mode not in self.MODES:
             raise ValueError(f"train precision must be one of {sorted(self.MODES)}")
-        L = _lib.lib()
-        self._prev = int(L.swn_train_get_precision())
-        _lib.check(L.swn_train_set_precision(self.MODES[mode]), "train_set_precision")
+        self._prev = _precision
+        _precision = self.MODES[mode]
 
     def __enter__(self):
         return self
 
     def __exit__(self, *exc):
-        _lib.check(_lib.lib().swn_train_set_precision(self._prev), "train_set_precision")
+        global _precision
+        _precision = self._prev
         return False
 
 
@@ -169,12 +179,12 @@ class HipNet:
     def decode(self, aux: torch.Tensor, n_steps: int, noise: Optional[torch.Tensor] = None,
                forced: Optional[torch.Tensor] = None, want_heads: bool = False, variant: int = 0,
                cond: Optional[torch.Tensor] = None, seed: Optional[torch.Tensor] = None, rng_seed: int = 0,
-               rng_utt0: int = 0, want_noise: bool = False):
+               rng_utt0: int = 0, want_noise: bool = False, utt_ids: Optional[Sequence[int]] = None):
         """run prologue + n_steps generation steps for every utterance of the batch.
 
         noise: laplace (B, n_steps, seg) | softmax (B, n_steps, Q), fp32, utterance-major - the host-drawn stream of
                the parity mode; None = the kernels draw it themselves (counter-based generator keyed by `rng_seed`,
-               utterance b drawing as global utterance `rng_utt0 + b`).
+               utterance b drawing as global utterance `utt_ids[b]` when given, else `rng_utt0 + b`).
         seed:  the seed waveform `audio` of batch_fast_generate: laplace (B, seg) fp32 | softmax (B,) classes; None =
                zeros / class Q/2.
         returns (out, heads): out laplace (B, n_steps*seg) fp32 | softmax (B, n_steps) int32; with want_noise=True
@@ -182,9 +192,10 @@ class HipNet:
         """
         if cond is None:
             cond = self.frontend(aux)
+        ids = None if utt_ids is None else torch.as_tensor(list(utt_ids), dtype=torch.int32)
         out, heads, used = _O.decode(self.packed, cond, noise, forced, seed, self.dlist, int(n_steps), int(variant),
                                      int(rng_seed) & 0x7FFFFFFFFFFFFFFF, int(rng_utt0) & 0xFFFFFFFF, bool(want_heads),
-                                     bool(want_noise))
+                                     bool(want_noise), ids)
         heads = heads if want_heads else None
         if want_noise:
             return out, heads, used
@@ -230,14 +241,16 @@ class HipNet:
         T = Tf * cfg.U
         Tp = T - 1 if soft else T - 2 * cfg.seg + 1
         audio = audio.to(self.device, torch.int32 if soft else torch.float32).contiguous()
-        if self.lib.swn_train_get_precision() == 1:
+        mode = current_precision()
+        if mode == _lib.PRECISION_BF16:
             res = self._bf16_train_forward(cond, audio, B, Tf)
             if res is not None:
                 out, wb, work = res
                 return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, work_bf16=wb, a_keep=self._a_keep,
-                                 B=B, Tf=Tf)
+                                 B=B, Tf=Tf, precision=mode, packed_version=self.packed_version)
         out, work, _ = _O.stack_forward(self.packed, cond, audio, self.dlist, False)
-        return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf)
+        return out, dict(aux=aux, cond=cond, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf, precision=mode,
+                         packed_version=self.packed_version)
 
     def _bf16_train_forward(self, cond, audio, B, Tf):
         """mixed-precision mode: bf16 forward -> (raw, bf16 work buffer, fp32 work buffer or None).  Returns None (caller
@@ -272,14 +285,14 @@ class HipNet:
                 _lib.check(L.swn_forward_bf16(d, _ptr(self.packed), _ptr(self._wbf16), _ptr(cond), _ptr(audio), B, Tf,
                                               _ptr(wb), _ptr(out), st), "forward_bf16")
         fused = self.fused_backward and _ops.backward_bf16_supported(self.dlist, B, Tf)
-        return out, wb, (None if fused else self._expand_bf16_work(wb, B, Tf))
+        return out, wb, (None if fused else self._expand_bf16_work(wb, B, Tf, _lib.PRECISION_BF16))
 
-    def _expand_bf16_work(self, wb, B, Tf):
+    def _expand_bf16_work(self, wb, B, Tf, mode):
         """bf16 work buffer of swn_forward_bf16 -> the fp32 work layout swn_backward reads (swn_bf16_work_to_f32)."""
         L, d = self.lib, ctypes.byref(self.desc)
         work = torch.empty(L.swn_forward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
         with _ops._on(self.device):
-            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), _stream_ptr(self.device)),
+            _lib.check(L.swn_bf16_work_to_f32(d, _ptr(self.packed), _ptr(wb), B, Tf, _ptr(work), int(mode), _stream_ptr(self.device)),
                        "bf16_work_to_f32")
         return work
 
@@ -310,17 +323,26 @@ class HipNet:
         d = ctypes.byref(self.desc)
         work = torch.empty(self.lib.swn_forward_drop_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
         out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
+        mode = current_precision()
         with _ops._on(self.device):
             _lib.check(self.lib.swn_forward_drop(d, _ptr(self.packed), _ptr(fe_work), _ptr(audio), B, Tf, _ptr(drop_x),
                                                  ctypes.cast(ptrs, ctypes.c_void_p), _ptr(work), _ptr(out), _ptr(None),
-                                                 _stream_ptr(self.device)), "forward_drop")
+                                                 mode, _stream_ptr(self.device)), "forward_drop")
         return out, dict(aux=aux, cond=None, fe_work=fe_work, audio=audio, work=work, B=B, Tf=Tf,
-                         drop=(drop_x, drop_h, ptrs))
+                         drop=(drop_x, drop_h, ptrs), precision=mode, packed_version=self.packed_version)
 
     def backward(self, saved, grad_raw: torch.Tensor) -> torch.Tensor:
-        """gradient of the loss wrt the packed parameter buffer, given d loss / d raw (B, n_out, Tp)."""
+        """gradient of the loss wrt the packed parameter buffer, given d loss / d raw (B, n_out, Tp).  Runs in the
+        arithmetic mode the forward that made `saved` ran in (the work-buffer layout of the dropout mode depends on it).
+        Raises if the parameters were re-packed since that forward (an optimizer step or load_state_dict between a
+        forward and its backward: torch's own in-place-modification error in the reference)."""
         L, d = self.lib, ctypes.byref(self.desc)
         B, Tf = saved["B"], saved["Tf"]
+        mode = int(saved.get("precision", current_precision()))
+        if saved.get("packed_version", self.packed_version) != self.packed_version:
+            raise RuntimeError("one of the parameters needed for gradient computation has been modified since the forward "
+                               "pass (the packed parameter buffer was refreshed in place: version "
+                               f"{self.packed_version}, the forward saw {saved['packed_version']})")
         grad_raw = grad_raw.to(self.device, torch.float32).contiguous()
         if saved.get("drop") is not None:
             drop_x, drop_h, ptrs = saved["drop"]
@@ -330,17 +352,17 @@ class HipNet:
                 _lib.check(L.swn_backward_drop(d, _ptr(self.packed), _ptr(saved["aux"]), _ptr(saved["fe_work"]),
                                                _ptr(saved["audio"]), _ptr(saved["work"]), _ptr(None), _ptr(drop_x),
                                                ctypes.cast(ptrs, ctypes.c_void_p), _ptr(grad_raw), B, Tf, _ptr(work),
-                                               _ptr(gp), _stream_ptr(self.device)), "backward_drop")
+                                               _ptr(gp), mode, _stream_ptr(self.device)), "backward_drop")
             return gp
         wb = saved.get("work_bf16")
-        if (wb is not None and self.fused_backward and L.swn_train_get_precision() == 1
+        if (wb is not None and self.fused_backward and mode == _lib.PRECISION_BF16
                 and _ops.backward_bf16_supported(self.dlist, B, Tf)):
             # BL6 class after a bf16 forward: the gated layers' backward fused per layer (csrc/swn_bwd_bl6.hip)
             return _ops.stack_backward_bf16_impl(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
                                                  wb, grad_raw, self.dlist)
         if saved["work"] is None:                      # the forward counted on the fused backward
-            saved["work"] = self._expand_bf16_work(wb, B, Tf)
-        if saved.get("a_keep") is not None and L.swn_train_get_precision() == 1:
+            saved["work"] = self._expand_bf16_work(wb, B, Tf, mode)
+        if saved.get("a_keep") is not None and mode == _lib.PRECISION_BF16:
             work = torch.empty(L.swn_backward_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
             gp = torch.empty_like(self.packed)
             with _ops._on(self.device):
@@ -349,7 +371,7 @@ class HipNet:
                                                _ptr(work), _ptr(gp), _stream_ptr(self.device)), "backward_keep")
             return gp
         return _ops.stack_backward_impl(self.packed, saved["aux"], saved["cond"], saved["fe_work"], saved["audio"],
-                                        saved["work"], grad_raw, self.dlist)
+                                        saved["work"], grad_raw, self.dlist, mode)
 
     def laplace_head_backward(self, raw, gmu, gb, glogb, ga, gb_clip=None, glogb_clip=None) -> torch.Tensor:
         return _ops.laplace_head_backward_impl(raw, gmu, gb, glogb, ga, gb_clip, glogb_clip, self.dlist)

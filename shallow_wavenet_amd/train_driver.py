@@ -374,7 +374,7 @@ def build_parser() -> argparse.ArgumentParser:
                         "the reference; ~0.1 s per chunk, ~1 s at cfg4's batch)")
     p.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                    help="arithmetic of the training step's contractions (not a reference flag): fp32 = parity mode, "
-                        "bf16 = bf16 operands with fp32 accumulation (swn_train_set_precision)")
+                        "bf16 = bf16 operands with fp32 accumulation (SWN_PRECISION_BF16)")
     return p
 
 
@@ -390,7 +390,15 @@ def _file_lists(wavs: str, feats: str):
 
 
 def main(argv=None) -> int:
+    """parse the stage's command line and run it with the training contractions in `--precision` (scoped to this call:
+    the C ABI holds no arithmetic mode, runtime.train_precision is host-side state restored on return)."""
+    from shallow_wavenet_amd.runtime import train_precision
     args = build_parser().parse_args(argv)
+    with train_precision(args.precision):
+        return _run(args)
+
+
+def _run(args) -> int:
     if args.GPU_device is not None:
         os.environ["HIP_VISIBLE_DEVICES"] = str(args.GPU_device)
     os.makedirs(args.expdir, exist_ok=True)
@@ -406,8 +414,6 @@ def main(argv=None) -> int:
         logging.error("gpu is not available. please check the setting.")
         return 1
     if args.precision != "fp32":
-        from shallow_wavenet_amd.runtime import train_precision
-        train_precision(args.precision)          # process-wide, for the whole run
         logging.info("training contractions in %s operands, fp32 accumulation" % args.precision)
     from shallow_wavenet_amd.nets.cswnv_shift1 import CSWNV, LaplaceLoss, LSDloss, initialize
     model = CSWNV(n_aux=args.n_aux, skip_chn=args.skip_chn, hid_chn=args.hid_chn, dilation_depth=args.dilation_depth,

@@ -28,7 +28,7 @@ def test_every_declared_symbol_is_exported_and_bound():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in _lib.py"
     assert set(_lib.SIGNATURES) == set(names)
-    assert lib.swn_abi_version() == 2
+    assert lib.swn_abi_version() == 3
     assert lib.swn_strerror(-1).decode().startswith("network descriptor")
 
 
@@ -42,13 +42,28 @@ def test_geometry_agrees_with_host_config(cfg):
     assert lib.swn_packed_floats(ctypes.byref(d)) > cfg.n_params() * 0.9
 
 
-def test_train_precision_switch_is_host_state():
-    """no GPU call behind it: include/swn_hip.h swn_train_set_precision / swn_train_get_precision"""
+def test_precision_is_a_call_argument_not_library_state():
+    """ABI 3: no process-wide arithmetic switch is exported; the training entry points take SWN_PRECISION_* and reject
+    anything else before touching a device (no GPU call behind this test)."""
     lib = _lib.lib()
-    assert lib.swn_train_get_precision() == 0
-    assert lib.swn_train_set_precision(1) == 0 and lib.swn_train_get_precision() == 1
-    assert lib.swn_train_set_precision(2) < 0 and lib.swn_train_get_precision() == 1
-    assert lib.swn_train_set_precision(0) == 0 and lib.swn_train_get_precision() == 0
+    assert not hasattr(lib, "swn_train_set_precision") and not hasattr(lib, "swn_train_get_precision")
+    d = _lib.desc_from_cfg(C.bl6_laplace())
+    r = ctypes.byref(d)
+    null = ctypes.c_void_p(None)
+    assert lib.swn_backward(r, null, null, null, null, null, null, null, null, 1, 1, null, null, 7, null) == -2
+    assert lib.swn_backward_drop(r, null, null, null, null, null, null, null, null, null, 1, 1, null, null, 2, null) == -2
+    assert lib.swn_forward_drop(r, null, null, null, 1, 1, null, null, null, null, null, -1, null) == -2
+    assert lib.swn_bf16_work_to_f32(r, null, null, 1, 1, null, 3, null) == -2
+    from shallow_wavenet_amd import runtime
+    assert runtime.current_precision() == _lib.PRECISION_FP32
+    with runtime.train_precision("bf16"):
+        assert runtime.current_precision() == _lib.PRECISION_BF16
+        with runtime.train_precision("fp32"):
+            assert runtime.current_precision() == _lib.PRECISION_FP32
+        assert runtime.current_precision() == _lib.PRECISION_BF16
+    assert runtime.current_precision() == _lib.PRECISION_FP32
+    with pytest.raises(ValueError):
+        runtime.train_precision("fp8")
 
 
 def test_bad_descriptors_are_rejected():

@@ -128,3 +128,96 @@ def test_driver_end_to_end_reproduces_the_reference_batch(gpu_ok, tmp_path, name
             pcm = np.frombuffer(w.readframes(w.getnframes()), dtype="<i2").astype(np.int64)
         want = np.rint(np.clip(ref[pos], -1, 1).astype(np.float64) * 32767.0).astype(np.int64)
         assert np.abs(pcm - want).max() <= (1 if kind == "laplace" else 0), (name, pos)
+
+
+def test_listing_dedupes_formats_and_skips_non_utterance_containers(tmp_path):
+    """an utterance present as x.npz and x.npy is decoded once; calc_stats' stats.npz in the tree is not an utterance."""
+    from shallow_wavenet_amd import featio
+    d = tmp_path / "feats"
+    d.mkdir()
+    a = np.arange(12, dtype=np.float32).reshape(4, 3)
+    np.save(str(d / "utt0.npy"), a)
+    featio.write_dataset(str(d / "utt0.npz"), "/feat_org_lf0", a)
+    featio.write_dataset(str(d / "utt1.npz"), "/feat_org_lf0", a)
+    featio.write_stats(str(d / "stats.npz"), "/feat_org_lf0", a.mean(0), a.std(0) + 1)
+    got = DD.list_features(str(d), "/feat_org_lf0")
+    assert [os.path.basename(f) for f in got] == ["utt0.npz", "utt1.npz"]
+    assert "stats.npz" in [os.path.basename(f) for f in DD.list_features(str(d))]       # without a dataset name: no probing
+
+
+def _tiny_run(tmp_path, kind, frames):
+    cfg = C.tiny(kind, 2, 4) if kind == "laplace" else C.tiny("softmax", wav_conv_flag=False)
+    feats = tmp_path / "feats"
+    feats.mkdir()
+    rng = np.random.default_rng(3)
+    for i, f in enumerate(frames):
+        np.save(str(feats / f"utt{i:02d}.npy"), rng.standard_normal((f, cfg.n_aux)).astype(np.float32))
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=7, flavor="trained" if kind == "laplace" else "xavier").items()}
+    torch.save({"model": sd}, str(tmp_path / "checkpoint-1.pkl"))
+    (tmp_path / "model.json").write_text(json.dumps(dict(cfg.to_dict(), string_path="/feat_org_lf0", audio_in=cfg.audio_in_flag)))
+    return cfg, ["--feats", str(feats), "--checkpoint", str(tmp_path / "checkpoint-1.pkl"), "--config", str(tmp_path / "model.json"),
+                 "--fs", "22050", "--verbose", "0"]
+
+
+def _clean_env(monkeypatch):
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        monkeypatch.delenv(k, raising=False)
+
+
+def test_n_gpus_fans_out_its_own_ranks(tmp_path, monkeypatch):
+    """`--n_gpus 2` as run.sh:675-684 passes it, no launcher around it: main() spawns the two ranks (the parent touches no
+    GPU), they meet in the one broadcast over gloo and each plans its np.array_split shard with global utterance indices."""
+    _clean_env(monkeypatch)
+    frames = [5, 3, 4, 6, 2]
+    cfg, argv = _tiny_run(tmp_path, "laplace", frames)
+    out = tmp_path / "plan"
+    rc = DD.main("laplace", argv + ["--outdir", str(out), "--n_gpus", "2", "--batch_size", "2", "--plan_only"])
+    assert rc == 0
+    plans = [json.load(open(out / f"decode.{r}.plan.json")) for r in range(2)]
+    assert [p["index"] for p in plans] == [[0, 1, 2], [3, 4]]                       # np.array_split of the unsorted list
+    assert [os.path.basename(f) for f in plans[1]["shard"]] == ["utt03.npy", "utt04.npy"]
+    assert plans[0]["rng_key"] == plans[1]["rng_key"]                               # one generator key for the whole run
+    assert plans[0]["packed_sum"] == plans[1]["packed_sum"] and plans[0]["packed_numel"] == plans[1]["packed_numel"] > 0
+    # rank 0: frames 5,3,4 sorted -> [utt01, utt02 | utt00]; each utterance keeps its position in the full list
+    assert plans[0]["batches"] == [{"ids": ["utt01", "utt02"], "n_samples": [3 * cfg.U, 4 * cfg.U], "utt_index": [1, 2]},
+                                   {"ids": ["utt00"], "n_samples": [5 * cfg.U], "utt_index": [0]}]
+    assert plans[1]["batches"] == [{"ids": ["utt04", "utt03"], "n_samples": [2 * cfg.U, 6 * cfg.U], "utt_index": [4, 3]}]
+    # the single-process plan covers the same utterances with the same indices and the same key
+    rc = DD.main("laplace", argv + ["--outdir", str(tmp_path / "plan1"), "--n_gpus", "1", "--batch_size", "2", "--plan_only"])
+    assert rc == 0
+    solo = json.load(open(tmp_path / "plan1" / "decode.0.plan.json"))
+    assert solo["index"] == [0, 1, 2, 3, 4] and solo["rng_key"] == plans[0]["rng_key"]
+    pair = {i: u for p in plans for b in p["batches"] for i, u in zip(b["ids"], b["utt_index"])}
+    assert pair == {i: u for b in solo["batches"] for i, u in zip(b["ids"], b["utt_index"])}
+
+
+def test_a_failing_rank_fails_the_fan_out(tmp_path, monkeypatch):
+    _clean_env(monkeypatch)
+    _, argv = _tiny_run(tmp_path, "laplace", [3, 2])
+    argv[argv.index("--checkpoint") + 1] = str(tmp_path / "missing.pkl")              # rank 0 cannot load it
+    rc = DD.main("laplace", argv + ["--outdir", str(tmp_path / "o"), "--n_gpus", "2", "--plan_only"])
+    assert rc != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["laplace", "softmax"])
+def test_device_noise_does_not_depend_on_n_gpus(gpu_ok, tmp_path, monkeypatch, kind):
+    """the same list decoded by one process and by `--n_gpus 2` (two spawned ranks; on a one-GPU box they share the card and
+    the broadcast runs over gloo) with `--noise_source device`: identical WAV files - an utterance's noise stream is keyed by
+    the run's one key and its position in the unsorted list, not by its shard or by where the length sort puts it."""
+    _clean_env(monkeypatch)
+    frames = [4, 2, 5, 3, 6]
+    cfg, argv = _tiny_run(tmp_path, kind, frames)
+    outs = []
+    for n in (1, 2):
+        out = tmp_path / f"wav{n}"
+        rc = DD.main(kind, argv + ["--outdir", str(out), "--n_gpus", str(n), "--batch_size", "1", "--seed", "5",
+                                   "--noise_source", "device"])
+        assert rc == 0
+        outs.append(out)
+    for i, f in enumerate(frames):
+        a, b = (open(o / f"utt{i:02d}.wav", "rb").read() for o in outs)
+        assert len(a) == 44 + 2 * f * cfg.U and a == b, (kind, i)
+    assert (outs[1] / "decode.0.log").exists() and (outs[1] / "decode.1.log").exists()
+    # and the streams differ between utterances (the index really enters the generator)
+    assert open(outs[0] / "utt00.wav", "rb").read()[44:200] != open(outs[0] / "utt03.wav", "rb").read()[44:200]

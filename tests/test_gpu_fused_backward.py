@@ -83,3 +83,58 @@ def test_unsupported_geometries_report_zero(gpu_ok):
     from shallow_wavenet_amd import ops
     for cfg in (C.bl6_laplace(2, 0), C.ref6_laplace(1, 4), C.bl6_softmax()):
         assert not ops.backward_bf16_supported(ops.desc_list(cfg), 2, 8)
+
+
+@pytest.mark.parametrize("U,frames,lpc", [(37, [9, 6, 4], 0), (112, [5, 3], 2)])
+def test_fused_backward_against_the_oracle_under_autograd(gpu_ok, U, frames, lpc):
+    """not a self-comparison: the fused path (module API, mixed-precision mode) against oracle/cpu_ref.py differentiated
+    by torch autograd on the host, at two ragged shapes - U = 37 (2 whole chunks + a 5-position tail per frame, utterances
+    zero-padded to different lengths) and U = 112 (the upper end of the covered range, lpc = 2).  Per parameter:
+    ||g - g_ref|| <= 5e-2 ||g_ref|| + 1e-3 of the largest tensor norm (the mixed-precision yardstick of
+    test_gpu_cfg4_full_size.py)."""
+    import dataclasses
+    from oracle import cpu_ref
+    from shallow_wavenet_amd import ops
+    from shallow_wavenet_amd.nets import cswnv_shift1 as mc
+    cfg = dataclasses.replace(C.bl6_laplace(1, lpc), upsampling_factor=U)
+    B, Tf = len(frames), max(frames)
+    sd = synth_state_dict(cfg, seed=6, flavor="trained", identity_scale_in=True)
+    aux_np = synth_aux(cfg, B, Tf, seed=7)
+    for b, f in enumerate(frames):
+        aux_np[b, :, f:] = 0.0
+    aux = torch.from_numpy(aux_np)
+    T = Tf * U
+    Tp = T - 2 * cfg.seg + 1
+    audio = torch.rand(B, 1, T - cfg.seg, generator=torch.Generator().manual_seed(2)) * 1.8 - 0.9
+    tgt = torch.rand(B, Tp, 1, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9
+    if lpc == 0:
+        tgt = tgt.reshape(B, Tp)
+
+    def loss_of(res, nll):
+        loss = nll(res[0], res[1], res[2])
+        return loss + 0.1 * res[3].pow(2).mean() if lpc > 0 else loss
+
+    P = cpu_ref.as_params(sd)
+    for v in P.values():
+        v.requires_grad_(True)
+    res_r = cpu_ref.laplace_forward(cfg, P, aux, audio)
+    loss_r = loss_of(res_r, lambda mu, b, lb: cpu_ref.laplace_nll(mu, b, tgt, log_b=lb))
+    loss_r.backward()
+
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    m.cuda().train()
+    assert ops.backward_bf16_supported(m._engine().dlist, B, Tf)
+    with train_precision("bf16"):
+        res = m(aux.cuda(), audio.cuda())
+        loss = loss_of(res, lambda mu, b, lb: mc.LaplaceLoss()(mu, b, tgt.cuda(), log_b=lb, log=False))
+        loss.backward()
+    assert m._engine().fused_backward, "the fused path is not the default"
+    assert abs(loss.item() - loss_r.item()) <= 5e-3 * max(1.0, abs(loss_r.item()))
+    big = max(float(np.linalg.norm(P[k].grad.numpy().ravel())) for k in P if P[k].grad is not None)
+    for k, p in m.named_parameters():
+        if P[k].grad is None:
+            continue
+        g, r = p.grad.double().cpu().numpy().ravel(), P[k].grad.double().numpy().ravel()
+        err = np.linalg.norm(g - r)
+        assert err <= 5e-2 * np.linalg.norm(r) + 1e-3 * big, (U, k, err, np.linalg.norm(r))

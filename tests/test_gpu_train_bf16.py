@@ -1,4 +1,4 @@
-"""GPU: mixed-precision mode of the backward contractions (swn_train_set_precision(1): bf16 operands, fp32
+"""GPU: mixed-precision mode of the training contractions (precision = SWN_PRECISION_BF16: bf16 operands, fp32
 accumulation) against the exact-fp32 mode of the same kernels and against the reference's own gradients.
 
 Tolerance (bf16 has 8 mantissa bits; products are summed in fp32): per parameter tensor
@@ -17,8 +17,8 @@ from shallow_wavenet_amd.synth import synth_aux, synth_state_dict
 
 pytestmark = pytest.mark.gpu
 
-LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_")) and "loss" in load_golden(n)[1]]
-SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_")) and "loss" in load_golden(n)[1]]
+LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_", "g9_")) and "loss" in load_golden(n)[1]]
+SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_", "g9_")) and "loss" in load_golden(n)[1]]
 
 
 def _grads(model):
@@ -31,16 +31,45 @@ def _close(name, got, ref, tol=2e-2, floor=1e-6):
         assert err <= tol * np.linalg.norm(r.ravel()) + floor, (name, k, err, np.linalg.norm(r.ravel()))
 
 
-def test_precision_switch_round_trips(gpu_ok):
-    from shallow_wavenet_amd import _lib
-    L = _lib.lib()
-    assert L.swn_train_get_precision() == 0
-    with train_precision("bf16"):
-        assert L.swn_train_get_precision() == 1
-    assert L.swn_train_get_precision() == 0
-    assert L.swn_train_set_precision(7) < 0
-    with pytest.raises(ValueError):
-        train_precision("fp8")
+def test_backward_runs_in_the_mode_of_its_forward(gpu_ok):
+    """the arithmetic mode is an argument of every call (ABI 3); a forward records it and its backward is issued in the
+    same mode even when the `train_precision` context has ended by then - in the dropout mode the work-buffer layout
+    depends on it (kept gate pre-activations), so a mismatch used to read uninitialised memory."""
+    from shallow_wavenet_amd import noise as swn_noise
+    from shallow_wavenet_amd.runtime import HipNet, current_precision
+    cfg = C.bl6_laplace(1, 0)
+    net = HipNet.from_state_dict(cfg, synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True), "cuda:0")
+    B, Tf = 2, 5
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    audio = (torch.rand(B, 1, Tf * cfg.U - cfg.seg, generator=torch.Generator().manual_seed(2)) * 1.8 - 0.9).cuda()
+    Tp = Tf * cfg.U - 2 * cfg.seg + 1
+    grad_raw = (torch.randn(B, cfg.n_out, Tp, generator=torch.Generator().manual_seed(4)) / Tp).cuda()
+    for drop in (None, swn_noise.dropout_masks(cfg, B, Tf, 0.5, generator=torch.Generator().manual_seed(6))):
+        with train_precision("bf16"):
+            _, saved = net.forward_train(aux, audio, drop=drop)
+            g_in = net.backward(saved, grad_raw).clone()
+            _, saved = net.forward_train(aux, audio, drop=drop)
+        assert current_precision() == 0 and saved["precision"] == 1
+        g_out = net.backward(saved, grad_raw)                 # after the context ended: still the forward's mode
+        assert torch.isfinite(g_out).all()
+        assert float((g_out - g_in).norm()) <= 1e-4 * float(g_in.norm()) + 1e-7     # float atomics reorder sums
+
+
+def test_backward_after_a_repack_raises(gpu_ok):
+    """a graph built before the parameters changed must not be back-propagated against the refreshed packed buffer
+    (the reference raises autograd's in-place-modification error there)."""
+    cfg = C.bl6_laplace(1, 0)
+    m = mc.CSWNV(**cfg.ctor_kwargs())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=3, flavor="trained").items()})
+    m.cuda().train()
+    aux = torch.from_numpy(synth_aux(cfg, 1, 3)).cuda()
+    audio = (torch.rand(1, 1, 3 * cfg.U - cfg.seg) * 1.8 - 0.9).cuda()
+    res = m(aux, audio)
+    with torch.no_grad():
+        m.out_2.bias.add_(0.5)
+    m(aux, audio)                       # notices the change and re-packs in place
+    with pytest.raises(RuntimeError, match="modified"):
+        res[0].sum().backward()
 
 
 @pytest.mark.parametrize("name", LAP)

@@ -97,7 +97,8 @@ def test_stage4_driver_runs_a_few_chunks_on_synthetic_data(gpu_ok, tmp_path, cap
                      "--do_prob", "0.5", "--wav_conv_flag", "true", "--epoch_count", "1", "--verbose", "1",
                      "--precision", precision])
     finally:
-        train_precision("fp32")            # the switch is process-wide: leave the parity mode on for the other tests
+        from shallow_wavenet_amd.runtime import current_precision
+        assert current_precision() == 0    # the driver scopes --precision to its own call
     assert rc == 0
     assert (exp / "model.conf").exists()
     text = caplog.text.lower()              # the driver's per-chunk loss lines (pytest owns the root logger, no file)
@@ -119,7 +120,8 @@ def test_stage7_softmax_driver_runs_a_few_chunks_on_synthetic_data(gpu_ok, tmp_p
                      "--upsampling_factor", "20", "--batch_size", "400", "--do_prob", "0.5", "--epoch_count", "1",
                      "--verbose", "1", "--precision", precision])
     finally:
-        train_precision("fp32")
+        from shallow_wavenet_amd.runtime import current_precision
+        assert current_precision() == 0
     assert rc == 0
     text = caplog.text.lower()
     assert "nan" not in text

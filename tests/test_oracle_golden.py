@@ -24,8 +24,8 @@ def _params(cfg, d):
     return cpu_ref.as_params(sd)
 
 
-LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_"))]
-SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_"))]
+LAP = [n for n in golden_names() if "_lap_" in n and not n.startswith(("g5_", "g6_", "g9_"))]
+SMX = [n for n in golden_names() if "softmax" in n and not n.startswith(("g5_", "g6_", "g9_"))]
 
 
 def test_fixture_inventory():
@@ -180,7 +180,7 @@ def test_geometry_matches_reference_modules():
     assert C.bl6_laplace().receptive_field == 64
 
 
-DROP = [n for n in golden_names() if n.startswith("g5_drop")]
+DROP = [n for n in golden_names() if n.startswith("g5_drop") or n.startswith("g9_drop")]
 
 
 @pytest.mark.parametrize("name", DROP)
@@ -258,6 +258,52 @@ def test_oracle_teacher_forced_ref6_forward_and_gradients(name):
         assert np.abs(ln[:, -64:] - d["fwd_logits_tail"]).max() <= 2e-5
         assert np.abs(ln[:, ::16] - d["fwd_logits_s16"]).max() <= 2e-5
         loss = torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), torch.from_numpy(d["loss_target"]).reshape(-1))
+    assert abs(loss.item() - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
+    loss.backward()
+    grads = {k: (P[k].grad.numpy() if P[k].grad is not None else np.zeros(tuple(P[k].shape), np.float32)) for k in P}
+    check_grads_against_fixture(name, grads, d)
+
+
+G9 = [n for n in golden_names() if n.startswith("g9_drop")]
+
+
+def drop_masks_of(cfg, d):
+    """the masks the reference drew for a g5 / g9 fixture (host stream, reference order)."""
+    from shallow_wavenet_amd import noise as swn_noise
+    torch.manual_seed(int(d["drop_seed"]))
+    do = bool(int(d["do"])) if "do" in d else True
+    return swn_noise.dropout_masks(cfg, d["aux"].shape[0], d["aux"].shape[2], float(d["drop_p"]), draw_x=do)
+
+
+def oracle_dropout_loss(cfg, P, d):
+    """loss of a g5 / g9 fixture through the oracle with the reference's masks -> (loss, outputs)."""
+    drop = drop_masks_of(cfg, d)
+    aux = torch.from_numpy(d["aux"])
+    if cfg.kind == "laplace":
+        res = cpu_ref.laplace_forward(cfg, P, aux, torch.from_numpy(d["fwd_audio"]), drop=drop)
+        loss = cpu_ref.laplace_nll(res[0], res[1], torch.from_numpy(d["loss_target"]), log_b=res[2])
+        if cfg.lpc > 0:
+            loss = loss + 0.1 * res[3].pow(2).mean()
+        return loss, res
+    raw, _ = cpu_ref.softmax_stack(cfg, P, torch.from_numpy(d["fwd_audio_idx"]), aux, drop=drop)
+    logits = raw.transpose(1, 2)
+    return torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), torch.from_numpy(d["loss_target"]).reshape(-1)), logits
+
+
+@pytest.mark.parametrize("name", G9)
+def test_oracle_dropout_mode_at_the_trained_geometries(name):
+    """G9: model.train(), forward(do=True), do_prob = 0.5 (run.sh:198) through the REFERENCE at REF6 Laplace / BL6 Laplace /
+    REF6 softmax; the oracle with the re-drawn masks, differentiated by autograd, gives its outputs, loss and gradients."""
+    cfg, d = load_golden(name)
+    assert len(G9) == 3 and float(d["drop_p"]) == 0.5
+    P = {k: v.clone().requires_grad_(True) for k, v in _params(cfg, d).items()}
+    loss, res = oracle_dropout_loss(cfg, P, d)
+    if cfg.kind == "laplace":
+        for i, r in enumerate(res):
+            assert np.abs(r.detach().numpy() - d[f"fwd_{i}"]).max() <= TOL, (name, i)
+    else:
+        ln = res.detach().numpy()
+        assert np.abs(ln[:, ::16] - d["fwd_logits_s16"]).max() <= 2e-5
     assert abs(loss.item() - float(d["loss"])) <= 1e-5 * max(1.0, abs(float(d["loss"])))
     loss.backward()
     grads = {k: (P[k].grad.numpy() if P[k].grad is not None else np.zeros(tuple(P[k].shape), np.float32)) for k in P}
