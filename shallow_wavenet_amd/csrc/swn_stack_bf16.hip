@@ -429,7 +429,11 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
         const unsigned base = (unsigned)(u.b * a.Tp + t0) * (H * 2u) + lane_h;
         const bool ok = t < u.te;
         const unsigned o1 = ok ? base : OOB;
+#ifdef SWN_NOTAP0
+        const unsigned o0 = (ok && t >= dil && dil == 12345) ? base - dil_bytes : OOB;
+#else
         const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
+#endif
         fr.b[0] = buf_ld_bf8(rh, o0); fr.b[1] = buf_ld_bf8(rh, o0 + 64u);
         fr.b[2] = buf_ld_bf8(rh, o1); fr.b[3] = buf_ld_bf8(rh, o1 + 64u);
     };
@@ -482,6 +486,9 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[4 + m][2 * p], ac[4 + m][2 * p + 1]};
+#ifdef SWN_NOEPI
+                    { const v2f o = az + acd; hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2)); continue; }
+#endif
                     const v2f pz = (wuz2 * cz2[p] + bz2[p]) * az, pc = (wuc2 * cc2[p] + bc2[p]) * acd;
                     const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
                     const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
@@ -501,7 +508,11 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
             uint4 o0, o1;
             o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
             o1.x = hw[4]; o1.y = hw[5]; o1.z = hw[6]; o1.w = hw[7];
+#ifdef SWN_NOSTORE
+            const unsigned so = (o0.x == 0x12345678u) ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h : OOB;
+#else
             const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h : OOB;
+#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rn, so + 64u, 0, 0);
         }
@@ -513,6 +524,456 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
     };
     unit_body(j0);
     for (int j = j0 + js; j < j1; j += js) unit_body(j);
+}
+
+// ---- half-channel variant of the frame-unit layer: TWO waves per SIMD ------------------------------------------------
+// A lone wave issues one vector instruction per 4 cycles where the SIMD could take one per 2 (MI355X_MICROARCH.md, row
+// 'vector-instruction ISSUE cost'), and the units kernel above IS bound by its vector issue (gate epilogue: 50 % of its
+// cycles, the cap of a lone wave; MFMA 22 %, waiting 29 %).  Here a 512-thread workgroup puts two waves on every SIMD:
+// a wave PAIR walks the units of one wave of the kernel above, wave hh of the pair owning channels [32 hh, 32 hh + 32)
+// - the M-tiles {2hh, 2hh+1} (gate) and {4+2hh, 4+2hh+1} (candidate) of the same permuted A image, 64 resident
+// registers instead of 128 - so that one wave's epilogue runs beside its partner's MFMAs and memory waits.  Both waves
+// load all four B fragments of a chunk (the second copy comes out of L1/L2: HBM traffic is unchanged); a lane finishes
+// the 8 channels of its own tap-1 fragment (chan_of: 32 hh + 8 g + 0..7) and stores them as ONE 16-byte piece.
+// The k-steps of a wave are ordered [tap0 lo, tap0 hi, tap1 OWN half, tap1 other half], so the code is the same for
+// both halves and only load offsets differ.  Units are at most 4 chunks (U > 64: two sub-units per frame).
+#define SWN_MF "v_mfma_f32_16x16x32_bf16 "
+template <bool B_ACC = true, class BT>
+__device__ __forceinline__ void mfma4_first(f32x4 (&acc)[4], const bf16x8 (&A)[4][4], const BT& b, const f32x4 (&c)[4]) {
+#define SWN_MF4F "s_nop 3\n\t" SWN_MF "%0, %4, %8, %9\n\t" SWN_MF "%1, %5, %8, %10\n\t" SWN_MF "%2, %6, %8, %11\n\t" \
+                 SWN_MF "%3, %7, %8, %12"
+    if (B_ACC)
+        asm(SWN_MF4F : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
+            : "a"(A[0][0]), "a"(A[1][0]), "a"(A[2][0]), "a"(A[3][0]), "a"(b), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+    else
+        asm(SWN_MF4F : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
+            : "a"(A[0][0]), "a"(A[1][0]), "a"(A[2][0]), "a"(A[3][0]), "v"(b), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
+#undef SWN_MF4F
+}
+template <int KS, bool TAIL, bool B_ACC>
+__device__ __forceinline__ void mfma4_next(f32x4 (&acc)[4], const bf16x8 (&A)[4][4], const bf16x8& b) {
+#define SWN_MF4 SWN_MF "%0, %4, %8, %0\n\t" SWN_MF "%1, %5, %8, %1\n\t" SWN_MF "%2, %6, %8, %2\n\t" SWN_MF "%3, %7, %8, %3"
+#define SWN_MF_OPS(BC) \
+        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) \
+        : "a"(A[0][KS]), "a"(A[1][KS]), "a"(A[2][KS]), "a"(A[3][KS]), BC(b)
+    // a k-step is four MFMAs (64 cycles of matrix pipe): the dependent MFMA of the next k-step is three instructions
+    // behind its producer, within the forwarding window of the same opcode; the tail waits for the MFMA -> VALU hazard
+    if (TAIL && B_ACC) asm("s_nop 3\n\t" SWN_MF4 "\n\ts_nop 15" SWN_MF_OPS("a"));
+    else if (TAIL) asm("s_nop 3\n\t" SWN_MF4 "\n\ts_nop 15" SWN_MF_OPS("v"));
+    else if (B_ACC) asm("s_nop 3\n\t" SWN_MF4 SWN_MF_OPS("a"));
+    else asm("s_nop 3\n\t" SWN_MF4 SWN_MF_OPS("v"));
+#undef SWN_MF_OPS
+#undef SWN_MF4
+}
+#undef SWN_MF
+
+struct CondHalf { float4 cz[2], cc[2]; };      // hoisted in_x rows of this lane's 8 channels (gate | candidate)
+
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void bf16_layer_half_kernel(const BfArgs a, const int l, const int dil,
+                                                                 const int n_units, const int Fu, const int SP) {
+    static_assert(NCH >= 1 && NCH <= 4, "units of at most four chunks");
+    __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | prescaled bx[128] of this layer
+    __shared__ float wus[128];                                       // upsampler taps (U <= 112)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = w & 1, pr = w >> 1;                               // channel half, pair index inside the workgroup
+    const int n = lane & 15, g = lane >> 4;
+    if (tid < 256)
+        cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid]
+                             : a.P[a.y.bx + (size_t)l * 128 + tid - 128] * (tid < 192 ? K_SIG : K_TANH);
+    else if (tid < 384) wus[tid - 256] = tid - 256 < a.U ? a.P[a.y.wup + tid - 256] : 0.f;
+    bf16x8 A[4][4];
+    {
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int mt = (t >> 1) * 4 + 2 * hh + (t & 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kk = ks < 2 ? ks : (ks == 2 ? 2 + hh : 3 - hh);       // own tap-1 half first
+                A[t][ks] = src[(mt * 4 + kk) * 64 + lane];
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 kbd[4];
+    float4 kbxz[2], kbxc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int ch = 32 * hh + 8 * g + 4 * m;                      // = chan_of(2 hh + m, g, 0)
+        kbd[m] = *reinterpret_cast<const f32x4*>(cst + ch);
+        kbd[2 + m] = *reinterpret_cast<const f32x4*>(cst + H + ch);
+        kbxz[m] = *reinterpret_cast<const float4*>(cst + 128 + ch);
+        kbxc[m] = *reinterpret_cast<const float4*>(cst + 128 + H + ch);
+    }
+    const size_t lstride = (size_t)a.B * a.Tp * H;
+    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(a.hs + (size_t)(l + 1) * lstride, lstride * 2);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
+    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u;
+    const unsigned own = 64u * (unsigned)hh, oth = 64u - own;        // byte offsets of the own / other channel half in a row
+    const unsigned lane_c = (unsigned)(32 * hh + 8 * g) * 4u;
+    const unsigned dil_bytes = (unsigned)dil * H * 2u;
+
+    const int js = gridDim.x * 4, j0 = blockIdx.x * 4 + pr, j1 = n_units;
+    if (j0 >= j1) return;
+
+    auto unit_of = [&](int j) -> Unit {                              // scalar
+        Unit u;
+        const bool ok = j < j1;
+        const int jc = ok ? j : j1 - 1;
+        const int fs = jc / SP, part = jc - fs * SP;
+        u.b = fs / Fu; u.f = fs - u.b * Fu;
+        const int s = u.f * a.U - a.coff, e = s + a.U;
+        const int ps = s + part * (16 * NCH), pe = ps + 16 * NCH < e ? ps + 16 * NCH : e;
+        u.ts = ps > 0 ? ps : 0;
+        u.te = ok ? (pe < a.Tp ? pe : a.Tp) : 0;
+        if (u.te < u.ts) u.te = u.ts;
+        u.jj0 = u.ts - s;
+        return u;
+    };
+    auto fetch_b = [&](const Unit& u, int i, BFrag& fr) {
+        const int t0 = u.ts + 16 * i, t = t0 + n;
+        const unsigned base = (unsigned)(u.b * a.Tp + t0) * (H * 2u) + lane_h;
+        const bool ok = t < u.te;
+        const unsigned o1 = ok ? base : OOB;
+#ifdef SWN_NOTAP0
+        const unsigned o0 = (ok && t >= dil && dil == 12345) ? base - dil_bytes : OOB;
+#else
+        const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
+#endif
+        fr.b[0] = buf_ld_bf8(rh, o0); fr.b[1] = buf_ld_bf8(rh, o0 + 64u);
+        fr.b[2] = buf_ld_bf8(rh, o1 + own); fr.b[3] = buf_ld_bf8(rh, o1 + oth);
+    };
+    auto fetch_rows = [&](const Unit& u, CondHalf& r) {
+        const int fc = u.f < a.Tf - 1 ? u.f : a.Tf - 1;
+        const unsigned off = (unsigned)((u.b * a.Tf + fc) * a.N + l * 128) * 4u + lane_c;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            r.cz[q] = buf_ld_f4(rc, off + (unsigned)(4 * q) * 4u);
+            r.cc[q] = buf_ld_f4(rc, off + (unsigned)(H + 4 * q) * 4u);
+        }
+    };
+
+    Unit cu = unit_of(j0), nu = unit_of(j0 + js);
+    CondHalf cur;
+    fetch_rows(cu, cur);
+    BFrag ring[NCH];
+#pragma unroll
+    for (int i = 0; i < NCH - 1; ++i) fetch_b(cu, i, ring[i]);
+    if (NCH == 1) fetch_b(cu, 0, ring[0]);
+    f32x4 acc[2][4];
+    mfma4_first(acc[0], A, ring[0].b[0], kbd);
+    mfma4_next<1, false, true>(acc[0], A, ring[0].b[1]);
+    mfma4_next<2, false, false>(acc[0], A, ring[0].b[2]);
+    mfma4_next<3, true, false>(acc[0], A, ring[0].b[3]);
+
+    auto unit_body = [&](const int j) __attribute__((always_inline)) {
+        CondHalf nxt;
+        fetch_rows(nu, nxt);
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            if (NCH > 1) {
+                if (i == 0) fetch_b(cu, NCH - 1, ring[NCH - 1]);     // slot freed by the previous unit's last chunk
+                else fetch_b(nu, i - 1, ring[i - 1]);                // slot freed by this unit's chunk i-1
+            }
+            const int t0 = cu.ts + 16 * i, t = t0 + n;
+            const float wu = wus[cu.jj0 + 16 * i + n];
+            const float wuz = wu * K_SIG, wuc = wu * K_TANH;
+            f32x4 (&ac)[4] = acc[i & 1];
+            f32x4 (&an)[4] = acc[(i + 1) & 1];
+            const BFrag& cb = ring[i];
+            unsigned hw[4];                                          // 8 finished channels, two bf16 per word
+            const u32x4 hpq = __builtin_bit_cast(u32x4, cb.b[2]);    // own tap-1 fragment: the highway input of these channels
+            auto epi = [&](const int m, const int p) __attribute__((always_inline)) {
+                const v2f cz2 = p ? (v2f){cur.cz[m].z, cur.cz[m].w} : (v2f){cur.cz[m].x, cur.cz[m].y};
+                const v2f cc2 = p ? (v2f){cur.cc[m].z, cur.cc[m].w} : (v2f){cur.cc[m].x, cur.cc[m].y};
+                const v2f bz2 = p ? (v2f){kbxz[m].z, kbxz[m].w} : (v2f){kbxz[m].x, kbxz[m].y};
+                const v2f bc2 = p ? (v2f){kbxc[m].z, kbxc[m].w} : (v2f){kbxc[m].x, kbxc[m].y};
+                const v2f wuz2 = {wuz, wuz}, wuc2 = {wuc, wuc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+                const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
+#ifdef SWN_NOEPI
+                { const v2f o = az + acd; hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2)); return; }
+#endif
+                const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
+                const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
+                const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
+                const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
+                const v2f q = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
+                const v2f cd = mtwo * q + one;
+                const unsigned hpw = hpq[m * 2 + p];
+                const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
+                const v2f o = z * (hp - cd) + cd;                                      // (1-z) c + z h
+                hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
+            };
+            if (NCH == 1) {
+                // one-chunk units: the next chunk is the next unit's, its fragments were requested a unit ago
+                epi(0, 0); epi(0, 1); epi(1, 0); epi(1, 1);
+            } else {
+                const BFrag& nb = ring[(i + 1) % NCH];               // i == NCH-1: slot 0 already holds (next unit, 0)
+                mfma4_first(an, A, nb.b[0], kbd);               epi(0, 0);
+                mfma4_next<1, false, true>(an, A, nb.b[1]);     epi(0, 1);
+                mfma4_next<2, false, false>(an, A, nb.b[2]);    epi(1, 0);
+                mfma4_next<3, true, false>(an, A, nb.b[3]);     epi(1, 1);
+            }
+            uint4 o0;
+            o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
+#ifdef SWN_NOSTORE
+            const unsigned so = (o0.x == 0x12345678u) ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h + own : OOB;
+#else
+            const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h + own : OOB;
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
+        }
+        if (NCH == 1) {
+            fetch_b(nu, 0, ring[0]);
+            mfma4_first(acc[0], A, ring[0].b[0], kbd);
+            mfma4_next<1, false, true>(acc[0], A, ring[0].b[1]);
+            mfma4_next<2, false, false>(acc[0], A, ring[0].b[2]);
+            mfma4_next<3, true, false>(acc[0], A, ring[0].b[3]);
+        } else if (NCH & 1) {                                        // odd chunk count: realign the accumulator parity
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[0][mt] = acc[1][mt];
+        }
+        cur = nxt; cu = nu; nu = unit_of(j + 2 * js);
+    };
+    unit_body(j0);
+    for (int j = j0 + js; j < j1; j += js) unit_body(j);
+}
+
+// ---- ring variant of the gated layer: two waves per SIMD AND a deep LDS-DMA ring ------------------------------------------
+// What bounds the register-ring kernels above is the number of UNIQUE bytes they keep in flight, not arithmetic: without
+// their epilogue they run 8 % faster, without their stores 9 %; 1 024 waves x 6 chunks x 2 KB = 12 MB in flight at the
+// ~2.5 us a loaded HBM read takes is the 4 TB/s they reach (Little's law), and every register spent on a deeper ring is
+// taken from a file that is already full.  Here the in-flight bytes cost no registers: a 512-thread workgroup (one per CU)
+// walks a CONTIGUOUS range of units and streams the hidden states of the next RA units into a 16-slot LDS ring with
+// `buffer_load_dwordx4 ... lds` (112 KB in flight per CU, ~28 MB on the chip), each 1-KiB piece laid down in MFMA
+// B-fragment order (lane (n, g) fetches position n, channels 8g.. of its half: the piece IS the fragment image), so
+//   * tap 1 is a lane-linear ds_read_b128, tap 0 (position t - dil) is the same image read at a rotated lane slot of this
+//     or one of the two previous units (conflict-free: a rotation inside 16-lane groups) - the layer's input leaves HBM/L2
+//     once, not twice, and no halo is re-loaded except two units at the head of a workgroup's range;
+//   * a unit = 4 chunks = one chunk per wave PAIR, wave hh of a pair owning channels [32 hh, 32 hh + 32) as in
+//     bf16_layer_half_kernel: two waves per SIMD, one wave's epilogue beside its partner's MFMAs;
+//   * every wave issues ONE piece per unit (chunk w >> 1, half w & 1), wave 0 also the unit's conditioning row; a wave waits
+//     for its own piece with a counted vmcnt, then ONE workgroup barrier per unit publishes all eight pieces and retires
+//     the slot that is overwritten next (LDS-DMA data is ordered for a reader by the issuer's vmcnt + a barrier,
+//     cdna_hip_programming.md 5 "Pipelining across barriers"; the DMA statements are asm, so hipcc adds no waits of its own).
+// Units are frame-aligned (U <= 64: a frame; 64 < U <= 112: two sub-units of 64 and U - 64 positions), so the hoisted
+// in_x row is uniform per unit; every unit takes one loop iteration of every wave, ragged and empty chunks are
+// out-of-range buffer offsets (zeros in, stores dropped).
+constexpr int RING_SLOTS = 16, RING_AHEAD = 14;          // slots j-1 .. j+RING_AHEAD live while unit j is finished
+constexpr int RING_UNIT_BYTES = 4 * 2048, RING_COND_BYTES = 1024;
+constexpr int RING_O_COND = RING_SLOTS * RING_UNIT_BYTES;                    // byte offsets inside the dynamic LDS block
+constexpr int RING_O_CST = RING_O_COND + RING_SLOTS * RING_COND_BYTES;       // bd[128] | prescaled bx[128] | wus[128]
+constexpr int RING_O_ZERO = RING_O_CST + 3 * 128 * 4;                        // 16 zero bytes (tap-0 reads before t = 0)
+constexpr int RING_LDS_BYTES = RING_O_ZERO + 16;
+typedef int v4i __attribute__((ext_vector_type(4)));
+
+// one 1-KiB LDS-DMA piece: lane i's 16 bytes land at lds_base + 16 i; voff = per-lane byte offset into the buffer
+// (out of range: zeros).  M0 carries the LDS base and is written in the statement that reads it.
+__device__ __forceinline__ void dma_piece(const v4i rsrc, unsigned voff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(lds_base) : "memory");
+}
+__device__ __forceinline__ v4i raw_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffull));
+    r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+
+struct RUnit { int b, f, part, ts, te; };          // wave-uniform: utterance, frame, sub-unit, [ts, te) positions
+
+__global__ __launch_bounds__(512, 2) void bf16_layer_ring_kernel(const BfArgs a, const int l, const int dil,
+                                                                 const int n_units, const int Fu, const int SP) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];     // ALL LDS of the kernel is this one block
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int hh = w & 1, pr = w >> 1;                               // channel half, chunk of the unit
+    const int n = lane & 15, g = lane >> 4;
+    float* cst = reinterpret_cast<float*>(ring + RING_O_CST);
+    if (tid < 256)
+        cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid]
+                             : a.P[a.y.bx + (size_t)l * 128 + tid - 128] * (tid < 192 ? K_SIG : K_TANH);
+    else if (tid < 384) cst[tid] = tid - 256 < a.U ? a.P[a.y.wup + tid - 256] : 0.f;
+    else if (tid < 388) reinterpret_cast<unsigned*>(ring + RING_O_ZERO)[tid - 384] = 0u;
+    bf16x8 A[4][4];
+    {
+        const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int mt = (t >> 1) * 4 + 2 * hh + (t & 1);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int kk = ks < 2 ? ks : (ks == 2 ? 2 + hh : 3 - hh);       // k-steps: tap0 lo, tap0 hi, tap1 own, tap1 other
+                A[t][ks] = src[(mt * 4 + kk) * 64 + lane];
+            }
+        }
+    }
+    __syncthreads();
+    f32x4 kbd[4];
+    float4 kbxz[2], kbxc[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const int ch = 32 * hh + 8 * g + 4 * m;
+        kbd[m] = *reinterpret_cast<const f32x4*>(cst + ch);
+        kbd[2 + m] = *reinterpret_cast<const f32x4*>(cst + H + ch);
+        kbxz[m] = *reinterpret_cast<const float4*>(cst + 128 + ch);
+        kbxc[m] = *reinterpret_cast<const float4*>(cst + 128 + H + ch);
+    }
+    const float* wus = cst + 256;
+    const size_t lstride = (size_t)a.B * a.Tp * H;
+    const v4i rh = raw_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
+    const v4i rcd = raw_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
+    const __amdgpu_buffer_rsrc_t rn = make_rsrc(a.hs + (size_t)(l + 1) * lstride, lstride * 2);
+    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u;
+    const unsigned own = 64u * (unsigned)hh;
+
+    // this workgroup's contiguous range of units
+    const int G = gridDim.x, k = blockIdx.x;
+    const int jb = (int)((long)n_units * k / G), je = (int)((long)n_units * (k + 1) / G);
+    if (jb >= je) return;
+
+    auto unit_at = [&](int j) -> RUnit {                             // scalar, with divisions: used to seed the two walkers
+        RUnit u;
+        const int jc = j < 0 ? 0 : j;
+        const int fs = jc / SP;
+        u.part = jc - fs * SP; u.b = fs / Fu; u.f = fs - u.b * Fu;
+        return u;
+    };
+    auto bounds = [&](RUnit& u, int j) {                             // positions of unit j (empty outside [0, n_units))
+        const int s = u.f * a.U - a.coff, e = s + a.U;
+        const int ps = s + u.part * 64, pe = ps + 64 < e ? ps + 64 : e;
+        u.ts = ps > 0 ? ps : 0;
+        u.te = (j >= 0 && j < n_units) ? (pe < a.Tp ? pe : a.Tp) : 0;
+        if (u.te < u.ts) u.te = u.ts;
+    };
+    auto advance = [&](RUnit& u) {
+        if (++u.part == SP) { u.part = 0; if (++u.f == Fu) { u.f = 0; ++u.b; } }
+    };
+    // DMA of unit j: this wave's piece (chunk pr, half hh) and, from wave 0, the unit's conditioning row
+    auto issue = [&](const RUnit& u, int j) {
+        const unsigned slot = (unsigned)(j - jb) & (RING_SLOTS - 1);
+        const int t = u.ts + 16 * pr + n;
+        const unsigned off = t < u.te ? (unsigned)(u.b * a.Tp + u.ts + 16 * pr) * (H * 2u) + lane_h + own : OOB;
+        dma_piece(rh, off, slot * RING_UNIT_BYTES + pr * 2048 + hh * 1024);
+        if (w == 0) {
+            const int fc = u.f < a.Tf - 1 ? u.f : a.Tf - 1;
+            const unsigned co = (lane < 32 && u.te > u.ts) ? (unsigned)((u.b * a.Tf + fc) * a.N + l * 128) * 4u + (unsigned)lane * 16u : OOB;
+            dma_piece(rcd, co, RING_O_COND + slot * RING_COND_BYTES);
+        }
+    };
+
+    // prologue: units jb-2 .. jb+RING_AHEAD-1 (the two in front are tap-0 sources only), all sixteen slots
+    for (int q = 0; q < RING_AHEAD + 2; ++q) {
+        const int jq = jb - 2 + q;
+        RUnit u = unit_at(jq);
+        bounds(u, jq);
+        issue(u, jq);
+    }
+    RUnit du = unit_at(jb + RING_AHEAD);                             // next unit the loop issues
+    RUnit cu = unit_at(jb), nu = unit_at(jb + 1);
+    bounds(cu, jb); bounds(nu, jb + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    struct Frags { bf16x8 b[4]; float4 cz[2], cc[2]; };
+    // fragments of this wave's chunk of unit j out of the ring: tap 0 of lane (n, g) is position t - dil
+    auto read_unit = [&](const RUnit& u, int j, Frags& fr) {
+        const unsigned slot = (unsigned)(j - jb) & (RING_SLOTS - 1);
+        const unsigned base = slot * RING_UNIT_BYTES + pr * 2048;
+        fr.b[2] = *reinterpret_cast<const bf16x8*>(ring + base + hh * 1024 + lane * 16);
+        fr.b[3] = *reinterpret_cast<const bf16x8*>(ring + base + (1 - hh) * 1024 + lane * 16);
+        // tap 0: frame offset of this lane's position, moved back by dil; a negative offset is in the previous frame
+        const int t = u.ts + 16 * pr + n;
+        int r = (u.ts + a.coff - u.f * a.U) + 16 * pr + n - dil;
+        int f0 = u.f, back = 0;                                      // back: how many units before j the source unit is
+        if (r < 0) { r += a.U; f0 -= 1; back = u.part + 1; }         // previous frame: its last sub-unit is (part + 1) units back ...
+        int part0 = (SP == 2 && r >= 64) ? 1 : 0;
+        if (f0 == u.f) back = u.part - part0;                        // same frame
+        else back += (SP - 1) - part0;                               // ... plus the sub-units of that frame behind the one hit
+        const int ts0 = f0 * a.U - a.coff + 64 * part0;
+        const int rel = ts0 >= 0 ? r - 64 * part0 : r - a.coff;      // position inside the source unit (unit 0 starts at t = 0)
+        const bool ok = t < u.te && t >= dil;
+        const unsigned s0 = (unsigned)(j - back - jb) & (RING_SLOTS - 1);
+        const unsigned a0 = ok ? s0 * RING_UNIT_BYTES + (unsigned)(rel >> 4) * 2048u + (unsigned)((rel & 15) + 16 * g) * 16u
+                               : (unsigned)RING_O_ZERO;
+        fr.b[0] = *reinterpret_cast<const bf16x8*>(ring + a0);
+        fr.b[1] = *reinterpret_cast<const bf16x8*>(ring + (ok ? a0 + 1024u : (unsigned)RING_O_ZERO));
+        const float* cr = reinterpret_cast<const float*>(ring + RING_O_COND + slot * RING_COND_BYTES);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            fr.cz[q] = *reinterpret_cast<const float4*>(cr + 32 * hh + 8 * g + 4 * q);
+            fr.cc[q] = *reinterpret_cast<const float4*>(cr + H + 32 * hh + 8 * g + 4 * q);
+        }
+    };
+
+    Frags cf, nf;
+    read_unit(cu, jb, cf);
+    f32x4 acc[2][4];
+    mfma4_first<false>(acc[0], A, cf.b[0], kbd);
+    mfma4_next<1, false, false>(acc[0], A, cf.b[1]);
+    mfma4_next<2, false, false>(acc[0], A, cf.b[2]);
+    mfma4_next<3, true, false>(acc[0], A, cf.b[3]);
+
+    auto body = [&](const int j, f32x4 (&ac)[4], f32x4 (&an)[4]) __attribute__((always_inline)) {
+        // this wave's piece of unit j+1 (issued RING_AHEAD-1 iterations ago) must have landed before the barrier: behind it
+        // in the queue are one store and RING_AHEAD-2 x (piece + store) - wave 0 also issues a conditioning piece per unit
+        if (w == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + 3 * (RING_AHEAD - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + 2 * (RING_AHEAD - 2)) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");                               // no LDS read of the loop may move above the barrier
+        __builtin_amdgcn_sched_barrier(0);
+        bounds(du, j + RING_AHEAD);
+        issue(du, j + RING_AHEAD);                                   // into the slot unit j-2 held (last read an iteration ago)
+        advance(du);
+        read_unit(nu, j + 1, nf);
+        const int t0 = cu.ts + 16 * pr, t = t0 + n;
+        int jj = cu.ts + a.coff - cu.f * a.U + 16 * pr + n;
+        jj = jj < 127 ? jj : 127;
+        const float wu = wus[jj];
+        const float wuz = wu * K_SIG, wuc = wu * K_TANH;
+        unsigned hw[4];
+        const u32x4 hpq = __builtin_bit_cast(u32x4, cf.b[2]);        // own tap-1 fragment: the highway input of these channels
+        auto epi = [&](const int m, const int p) __attribute__((always_inline)) {
+            const v2f cz2 = p ? (v2f){cf.cz[m].z, cf.cz[m].w} : (v2f){cf.cz[m].x, cf.cz[m].y};
+            const v2f cc2 = p ? (v2f){cf.cc[m].z, cf.cc[m].w} : (v2f){cf.cc[m].x, cf.cc[m].y};
+            const v2f bz2 = p ? (v2f){kbxz[m].z, kbxz[m].w} : (v2f){kbxz[m].x, kbxz[m].y};
+            const v2f bc2 = p ? (v2f){kbxc[m].z, kbxc[m].w} : (v2f){kbxc[m].x, kbxc[m].y};
+            const v2f wuz2 = {wuz, wuz}, wuc2 = {wuc, wuc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+            const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
+            const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
+            const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
+            const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
+            const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
+            const v2f q = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
+            const v2f cd = mtwo * q + one;
+            const unsigned hpw = hpq[m * 2 + p];
+            const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
+            const v2f o = z * (hp - cd) + cd;                                      // (1-z) c + z h
+            hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
+        };
+        mfma4_first<false>(an, A, nf.b[0], kbd);        epi(0, 0);
+        mfma4_next<1, false, false>(an, A, nf.b[1]);    epi(0, 1);
+        mfma4_next<2, false, false>(an, A, nf.b[2]);    epi(1, 0);
+        mfma4_next<3, true, false>(an, A, nf.b[3]);     epi(1, 1);
+        uint4 o0;
+        o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
+        const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h + own : OOB;
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
+        cf = nf; cu = nu;
+        advance(nu); bounds(nu, j + 2);
+    };
+    int j = jb;
+    for (; j + 1 < je; j += 2) { body(j, acc[0], acc[1]); body(j + 1, acc[1], acc[0]); }
+    if (j < je) body(j, acc[0], acc[1]);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // pieces of units past the range are still landing
 }
 
 // ---- head: skip (K = L*64) -> relu -> out_1 (128x128) -> relu -> out_2 (<=16 x 128) ----------------
@@ -760,6 +1221,40 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     const int n_chunks = batch * (int)((Tp + 15) / 16);
     const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
     const int nch = (g.U + 15) / 16;
+#if defined(SWN_RING_LAYER)          // experimental: see bf16_layer_ring_kernel
+    if (g.seg == 1 && g.U >= 32 && nch <= 7) {
+        // LDS-DMA ring, two waves per SIMD (bf16_layer_ring_kernel): one workgroup per CU walks a contiguous range of units
+        const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frames per utterance
+        const int SP = nch > 4 ? 2 : 1;
+        const int n_units = batch * Fu * SP;
+        const int ug = n_units < 256 ? n_units : 256;
+        static bool attr_set = false;
+        if (!attr_set) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_layer_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    RING_LDS_BYTES) != hipSuccess) return SWN_E_LAUNCH;
+            attr_set = true;
+        }
+        for (int l = 0; l < g.L; ++l)
+            hipLaunchKernelGGL(bf16_layer_ring_kernel, dim3(ug), dim3(512), RING_LDS_BYTES, st, a, l, g.dil[l], n_units, Fu, SP);
+    } else
+#endif
+#if defined(SWN_HALF_UNITS)         // experimental: see bf16_layer_half_kernel
+    if (g.seg == 1 && g.U >= 16 && nch <= 7) {
+        // two waves per SIMD, a wave pair per unit (bf16_layer_half_kernel): units of at most four chunks
+        const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frames per utterance
+        const int SP = nch > 4 ? 2 : 1, NCH = (nch + SP - 1) / SP;
+        const int n_units = batch * Fu * SP;
+        const int ug = (n_units + 3) / 4 < 256 ? (n_units + 3) / 4 : 256;       // one 512-thread workgroup per CU
+        for (int l = 0; l < g.L; ++l) {
+            switch (NCH) {
+                case 1: hipLaunchKernelGGL(bf16_layer_half_kernel<1>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
+                case 2: hipLaunchKernelGGL(bf16_layer_half_kernel<2>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
+                case 3: hipLaunchKernelGGL(bf16_layer_half_kernel<3>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
+                default: hipLaunchKernelGGL(bf16_layer_half_kernel<4>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
+            }
+        }
+    } else
+#endif
     if (g.seg == 1 && g.U >= 16 && nch <= 7) {
         const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frame units per utterance
         const int n_units = batch * Fu;
