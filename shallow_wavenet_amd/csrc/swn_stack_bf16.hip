@@ -742,39 +742,39 @@ __global__ __launch_bounds__(512, 2) void bf16_layer_half_kernel(const BfArgs a,
     for (int j = j0 + js; j < j1; j += js) unit_body(j);
 }
 
-// ---- ring variant of the gated layer: two waves per SIMD AND a deep LDS-DMA ring ------------------------------------------
-// What bounds the register-ring kernels above is the number of UNIQUE bytes they keep in flight, not arithmetic: without
-// their epilogue they run 8 % faster, without their stores 9 %; 1 024 waves x 6 chunks x 2 KB = 12 MB in flight at the
-// ~2.5 us a loaded HBM read takes is the 4 TB/s they reach (Little's law), and every register spent on a deeper ring is
-// taken from a file that is already full.  Here the in-flight bytes cost no registers: a 512-thread workgroup (one per CU)
-// walks a CONTIGUOUS range of units and streams the hidden states of the next RA units into a 16-slot LDS ring with
-// `buffer_load_dwordx4 ... lds` (112 KB in flight per CU, ~28 MB on the chip), each 1-KiB piece laid down in MFMA
-// B-fragment order (lane (n, g) fetches position n, channels 8g.. of its half: the piece IS the fragment image), so
-//   * tap 1 is a lane-linear ds_read_b128, tap 0 (position t - dil) is the same image read at a rotated lane slot of this
-//     or one of the two previous units (conflict-free: a rotation inside 16-lane groups) - the layer's input leaves HBM/L2
-//     once, not twice, and no halo is re-loaded except two units at the head of a workgroup's range;
-//   * a unit = 4 chunks = one chunk per wave PAIR, wave hh of a pair owning channels [32 hh, 32 hh + 32) as in
-//     bf16_layer_half_kernel: two waves per SIMD, one wave's epilogue beside its partner's MFMAs;
-//   * every wave issues ONE piece per unit (chunk w >> 1, half w & 1), wave 0 also the unit's conditioning row; a wave waits
-//     for its own piece with a counted vmcnt, then ONE workgroup barrier per unit publishes all eight pieces and retires
-//     the slot that is overwritten next (LDS-DMA data is ordered for a reader by the issuer's vmcnt + a barrier,
-//     cdna_hip_programming.md 5 "Pipelining across barriers"; the DMA statements are asm, so hipcc adds no waits of its own).
-// Units are frame-aligned (U <= 64: a frame; 64 < U <= 112: two sub-units of 64 and U - 64 positions), so the hoisted
-// in_x row is uniform per unit; every unit takes one loop iteration of every wave, ragged and empty chunks are
-// out-of-range buffer offsets (zeros in, stores dropped).
-constexpr int RING_SLOTS = 16, RING_AHEAD = 14;          // slots j-1 .. j+RING_AHEAD live while unit j is finished
-constexpr int RING_UNIT_BYTES = 4 * 2048, RING_COND_BYTES = 1024;
-constexpr int RING_O_COND = RING_SLOTS * RING_UNIT_BYTES;                    // byte offsets inside the dynamic LDS block
-constexpr int RING_O_CST = RING_O_COND + RING_SLOTS * RING_COND_BYTES;       // bd[128] | prescaled bx[128] | wus[128]
-constexpr int RING_O_ZERO = RING_O_CST + 3 * 128 * 4;                        // 16 zero bytes (tap-0 reads before t = 0)
-constexpr int RING_LDS_BYTES = RING_O_ZERO + 16;
+// ---- depth-fused gated stack: all six layers of a position range in ONE launch ---------------------------------------------
+// Per-layer launches move every hidden state through HBM twice (written by layer l, read by layer l+1) and pay a launch, a
+// weight fetch per wave and a drain per layer - at BASELINE cfg4's own 8 x 16 500 that fixed part is most of a 16 us launch.
+// What bounds the per-layer kernels above is not arithmetic either (without their epilogue they run 8 % faster, without their
+// stores 9 %): it is the unique bytes they keep in flight.  Here a 768-thread workgroup (one per CU) walks a CONTIGUOUS range of
+// conditioning frames; wave (l, hh) owns layer l and the channels [32 hh, 32 hh + 32) (64 resident A registers, the M-tiles of
+// bf16_layer_half_kernel), and the twelve waves step through the chunk sequence in lock-step, layer l one chunk behind layer l-1:
+//   * h0 arrives by LDS-DMA (`buffer_load_dwordx4 ... lds`, 8 chunks ahead, each 1-KiB piece laid down in MFMA B-fragment
+//     order: lane (n, g) fetches position n, channels 8g.. of its half - the piece IS the fragment image);
+//   * a layer's output chunk-half is ONE ds_write_b128 per lane into the next level's 8-chunk LDS ring - the same fragment
+//     image, because a lane finishes exactly the 16 bytes of its own tap-1 fragment - and one 16-byte store to HBM (the head
+//     and the backward read every level); the next layer reads tap 1 lane-linearly and tap 0 (position t - dil) at a rotated
+//     lane slot of an earlier chunk (conflict-free: a rotation inside 16-lane groups).  Hidden states are READ from HBM once
+//     (h0) instead of six times;
+//   * one workgroup barrier per step; LDS-DMA data is ordered for its readers by the issuer's counted vmcnt + that barrier
+//     (cdna_hip_programming.md 5 "Pipelining across barriers"; the DMA statements are asm, so hipcc adds no waits of its own);
+//   * a range starts FZ_HALO chunks early (the stack reaches 63 positions back); halo chunks are computed, not stored.
+// Chunks are frame-aligned (NCF = ceil(U / 16) per conditioning frame, the last one ragged), so the hoisted in_x row is
+// uniform per chunk.  Frames 0 and 1 of an utterance (zero padding in front, frame 0 shorter by `coff`) take a general path.
+constexpr int FZ_L0_SLOTS = 16, FZ_L0_AHEAD = 8, FZ_LV_SLOTS = 8, FZ_COND_SLOTS = 4, FZ_HALO = 5, FZ_NL = 6;
+constexpr int FZ_O_LV = FZ_L0_SLOTS * 2048;                                  // levels 1..5 behind level 0
+constexpr int FZ_O_COND = FZ_O_LV + (FZ_NL - 1) * FZ_LV_SLOTS * 2048;        // [layer][frame & 3][1 KB piece]
+constexpr int FZ_O_CST = FZ_O_COND + FZ_NL * FZ_COND_SLOTS * 1024;           // [layer][bd 128 | prescaled bx 128] floats
+constexpr int FZ_O_WUS = FZ_O_CST + FZ_NL * 256 * 4;                         // upsampler taps, 128 floats
+constexpr int FZ_O_ZERO = FZ_O_WUS + 128 * 4;                                // 16 zero bytes (tap-0 reads before t = 0)
+constexpr int FZ_LDS_BYTES = FZ_O_ZERO + 16;
 typedef int v4i __attribute__((ext_vector_type(4)));
 
-// one 1-KiB LDS-DMA piece: lane i's 16 bytes land at lds_base + 16 i; voff = per-lane byte offset into the buffer
-// (out of range: zeros).  M0 carries the LDS base and is written in the statement that reads it.
-__device__ __forceinline__ void dma_piece(const v4i rsrc, unsigned voff, unsigned lds_base) {
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(lds_base) : "memory");
+// one 1-KiB LDS-DMA piece: lane i's 16 bytes land at lds_base + 16 i; voff (per lane; the range check is on it) + soff =
+// byte offset into the buffer, out of range: zeros.  M0 carries the LDS base and is written in the statement that reads it.
+__device__ __forceinline__ void dma_piece(const v4i rsrc, unsigned voff, unsigned soff, unsigned lds_base) {
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "memory");
 }
 __device__ __forceinline__ v4i raw_rsrc(const void* p, size_t bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -786,21 +786,24 @@ __device__ __forceinline__ v4i raw_rsrc(const void* p, size_t bytes) {
     return r;
 }
 
-struct RUnit { int b, f, part, ts, te; };          // wave-uniform: utterance, frame, sub-unit, [ts, te) positions
+struct FzPos { int j, c, b, f; };                  // wave-uniform walker: global frame, chunk in frame, utterance, frame in utterance
 
-__global__ __launch_bounds__(512, 2) void bf16_layer_ring_kernel(const BfArgs a, const int l, const int dil,
-                                                                 const int n_units, const int Fu, const int SP) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char ring[];     // ALL LDS of the kernel is this one block
+__global__ __launch_bounds__(768) void bf16_stack_fused_kernel(const BfArgs a, const int n_frames_all, const int Fu) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];      // ALL LDS of the kernel is this one block
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = w & 1, pr = w >> 1;                               // channel half, chunk of the unit
+    const int l = w >> 1, hh = w & 1;                                // layer, channel half
     const int n = lane & 15, g = lane >> 4;
-    float* cst = reinterpret_cast<float*>(ring + RING_O_CST);
-    if (tid < 256)
-        cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid]
-                             : a.P[a.y.bx + (size_t)l * 128 + tid - 128] * (tid < 192 ? K_SIG : K_TANH);
-    else if (tid < 384) cst[tid] = tid - 256 < a.U ? a.P[a.y.wup + tid - 256] : 0.f;
-    else if (tid < 388) reinterpret_cast<unsigned*>(ring + RING_O_ZERO)[tid - 384] = 0u;
+    const int U = a.U, coff = a.coff, NCF = (U + 15) >> 4, dil = 1 << l;     // BL6 class: K = 2, dilations 1 .. 32
+    float* cst = reinterpret_cast<float*>(lds + FZ_O_CST);
+    for (int e = tid; e < FZ_NL * 256; e += 768) {
+        const int ll = e >> 8, r = e & 255;
+        cst[e] = r < 128 ? a.P[a.y.bd + (size_t)ll * 128 + r] : a.P[a.y.bx + (size_t)ll * 128 + r - 128] * (r < 192 ? K_SIG : K_TANH);
+    }
+    if (tid < 128) reinterpret_cast<float*>(lds + FZ_O_WUS)[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
+    if (tid < 4) reinterpret_cast<unsigned*>(lds + FZ_O_ZERO)[tid] = 0u;
+    // the rings start as zeros: the first chunks read tap-0 slots no producer has written (nothing real depends on them)
+    for (int e = tid; e < FZ_O_COND / 16; e += 768) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
     bf16x8 A[4][4];
     {
         const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
@@ -815,165 +818,161 @@ __global__ __launch_bounds__(512, 2) void bf16_layer_ring_kernel(const BfArgs a,
         }
     }
     __syncthreads();
+    const unsigned lc = (unsigned)(32 * hh + 8 * g) * 4u;            // this lane's 8 channels inside a 128-float row
     f32x4 kbd[4];
-    float4 kbxz[2], kbxc[2];
 #pragma unroll
     for (int m = 0; m < 2; ++m) {
-        const int ch = 32 * hh + 8 * g + 4 * m;
-        kbd[m] = *reinterpret_cast<const f32x4*>(cst + ch);
-        kbd[2 + m] = *reinterpret_cast<const f32x4*>(cst + H + ch);
-        kbxz[m] = *reinterpret_cast<const float4*>(cst + 128 + ch);
-        kbxc[m] = *reinterpret_cast<const float4*>(cst + 128 + H + ch);
+        kbd[m] = *reinterpret_cast<const f32x4*>(lds + FZ_O_CST + l * 1024 + lc + 16 * m);
+        kbd[2 + m] = *reinterpret_cast<const f32x4*>(lds + FZ_O_CST + l * 1024 + H * 4 + lc + 16 * m);
     }
-    const float* wus = cst + 256;
     const size_t lstride = (size_t)a.B * a.Tp * H;
-    const v4i rh = raw_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
+    const v4i rh0 = raw_rsrc(a.hs, lstride * 2);
     const v4i rcd = raw_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
     const __amdgpu_buffer_rsrc_t rn = make_rsrc(a.hs + (size_t)(l + 1) * lstride, lstride * 2);
-    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u;
-    const unsigned own = 64u * (unsigned)hh;
+    const unsigned lane_row = (unsigned)(n * H + 8 * g) * 2u + 64u * (unsigned)hh;     // own 16 bytes of position n's row
+    const unsigned lane_lds = (unsigned)lane * 16u;
+    const unsigned cond_voff = lane < 32 ? (unsigned)lane * 16u : OOB;
+    const unsigned in_base = l == 0 ? 0u : (unsigned)(FZ_O_LV + (l - 1) * FZ_LV_SLOTS * 2048);   // ring of this layer's input level
+    const unsigned in_mask = l == 0 ? FZ_L0_SLOTS - 1 : FZ_LV_SLOTS - 1;
+    const unsigned out_base = (unsigned)(FZ_O_LV + l * FZ_LV_SLOTS * 2048);                       // l < 5 only
 
-    // this workgroup's contiguous range of units
+    // this workgroup's contiguous range of frames, entered FZ_HALO chunks early
     const int G = gridDim.x, k = blockIdx.x;
-    const int jb = (int)((long)n_units * k / G), je = (int)((long)n_units * (k + 1) / G);
+    const int jb = (int)((long)n_frames_all * k / G), je = (int)((long)n_frames_all * (k + 1) / G);
     if (jb >= je) return;
-
-    auto unit_at = [&](int j) -> RUnit {                             // scalar, with divisions: used to seed the two walkers
-        RUnit u;
-        const int jc = j < 0 ? 0 : j;
-        const int fs = jc / SP;
-        u.part = jc - fs * SP; u.b = fs / Fu; u.f = fs - u.b * Fu;
-        return u;
+    const int hf = (FZ_HALO + NCF - 1) / NCF;                        // frames the halo reaches back
+    const int NQ = FZ_HALO + (je - jb) * NCF;                        // chunks every layer walks; chunk number 0 is (jb - hf, hf NCF - FZ_HALO)
+    auto pos_at = [&](int q) -> FzPos {                              // scalar, with divisions: seeds a walker
+        FzPos p;
+        const int qq = q + hf * NCF - FZ_HALO;                       // chunks since the start of frame jb - hf
+        p.j = jb - hf + qq / NCF; p.c = qq - (qq / NCF) * NCF;
+        const int jc = p.j < 0 ? 0 : p.j;
+        p.b = jc / Fu; p.f = jc - p.b * Fu;
+        return p;
     };
-    auto bounds = [&](RUnit& u, int j) {                             // positions of unit j (empty outside [0, n_units))
-        const int s = u.f * a.U - a.coff, e = s + a.U;
-        const int ps = s + u.part * 64, pe = ps + 64 < e ? ps + 64 : e;
-        u.ts = ps > 0 ? ps : 0;
-        u.te = (j >= 0 && j < n_units) ? (pe < a.Tp ? pe : a.Tp) : 0;
-        if (u.te < u.ts) u.te = u.ts;
+    auto advance = [&](FzPos& p) {
+        if (++p.c == NCF) { p.c = 0; ++p.j; if (p.j > 0 && ++p.f == Fu) { p.f = 0; ++p.b; } }
     };
-    auto advance = [&](RUnit& u) {
-        if (++u.part == SP) { u.part = 0; if (++u.f == Fu) { u.f = 0; ++u.b; } }
+    auto first_pos = [&](const FzPos& p) -> int { const int s = p.f * U - coff; return s > 0 ? s : 0; };
+    auto real = [&](const FzPos& p) -> bool { return p.j >= 0 && p.j < n_frames_all; };
+    // level-0 piece of chunk q (waves of layer 0: half hh each); lanes past the frame's end fetch positions nobody uses
+    auto issue_h0 = [&](const FzPos& p, int q) {
+        const bool ok = real(p) && q < NQ;
+        dma_piece(rh0, ok ? lane_row : OOB, ok ? (unsigned)(p.b * a.Tp + first_pos(p) + 16 * p.c) * (H * 2u) : 0u,
+                  ((unsigned)q & (FZ_L0_SLOTS - 1)) * 2048u + hh * 1024u);
     };
-    // DMA of unit j: this wave's piece (chunk pr, half hh) and, from wave 0, the unit's conditioning row
-    auto issue = [&](const RUnit& u, int j) {
-        const unsigned slot = (unsigned)(j - jb) & (RING_SLOTS - 1);
-        const int t = u.ts + 16 * pr + n;
-        const unsigned off = t < u.te ? (unsigned)(u.b * a.Tp + u.ts + 16 * pr) * (H * 2u) + lane_h + own : OOB;
-        dma_piece(rh, off, slot * RING_UNIT_BYTES + pr * 2048 + hh * 1024);
-        if (w == 0) {
-            const int fc = u.f < a.Tf - 1 ? u.f : a.Tf - 1;
-            const unsigned co = (lane < 32 && u.te > u.ts) ? (unsigned)((u.b * a.Tf + fc) * a.N + l * 128) * 4u + (unsigned)lane * 16u : OOB;
-            dma_piece(rcd, co, RING_O_COND + slot * RING_COND_BYTES);
-        }
+    // conditioning row of this layer for frame (j, b, f) (waves hh == 0)
+    auto issue_cond = [&](int j, int b, int f) {
+        const bool ok = j >= 0 && j < n_frames_all;
+        const int fc = f < a.Tf - 1 ? f : a.Tf - 1;
+        dma_piece(rcd, ok ? cond_voff : OOB, ok ? (unsigned)((b * a.Tf + fc) * a.N + l * 128) * 4u : 0u,
+                  (unsigned)(FZ_O_COND + (l * FZ_COND_SLOTS + (j & (FZ_COND_SLOTS - 1))) * 1024));
     };
 
-    // prologue: units jb-2 .. jb+RING_AHEAD-1 (the two in front are tap-0 sources only), all sixteen slots
-    for (int q = 0; q < RING_AHEAD + 2; ++q) {
-        const int jq = jb - 2 + q;
-        RUnit u = unit_at(jq);
-        bounds(u, jq);
-        issue(u, jq);
+    FzPos cp = pos_at(0);                                            // the chunk this wave processes next
+    FzPos dp = cp;                                                   // layer-0 waves: the chunk whose piece is issued next
+    if (l == 0) {
+        for (int q = 0; q < FZ_L0_AHEAD; ++q) { issue_h0(dp, q); advance(dp); }
     }
-    RUnit du = unit_at(jb + RING_AHEAD);                             // next unit the loop issues
-    RUnit cu = unit_at(jb), nu = unit_at(jb + 1);
-    bounds(cu, jb); bounds(nu, jb + 1);
+    if (hh == 0) {                                                   // rows of the first two frames; the loop stays two frames ahead
+        issue_cond(cp.j, cp.b, cp.f);
+        FzPos np = cp; np.c = NCF - 1; advance(np);                  // first chunk of the next frame
+        issue_cond(np.j, np.b, np.f);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    struct Frags { bf16x8 b[4]; float4 cz[2], cc[2]; };
-    // fragments of this wave's chunk of unit j out of the ring: tap 0 of lane (n, g) is position t - dil
-    auto read_unit = [&](const RUnit& u, int j, Frags& fr) {
-        const unsigned slot = (unsigned)(j - jb) & (RING_SLOTS - 1);
-        const unsigned base = slot * RING_UNIT_BYTES + pr * 2048;
-        fr.b[2] = *reinterpret_cast<const bf16x8*>(ring + base + hh * 1024 + lane * 16);
-        fr.b[3] = *reinterpret_cast<const bf16x8*>(ring + base + (1 - hh) * 1024 + lane * 16);
-        // tap 0: frame offset of this lane's position, moved back by dil; a negative offset is in the previous frame
-        const int t = u.ts + 16 * pr + n;
-        int r = (u.ts + a.coff - u.f * a.U) + 16 * pr + n - dil;
-        int f0 = u.f, back = 0;                                      // back: how many units before j the source unit is
-        if (r < 0) { r += a.U; f0 -= 1; back = u.part + 1; }         // previous frame: its last sub-unit is (part + 1) units back ...
-        int part0 = (SP == 2 && r >= 64) ? 1 : 0;
-        if (f0 == u.f) back = u.part - part0;                        // same frame
-        else back += (SP - 1) - part0;                               // ... plus the sub-units of that frame behind the one hit
-        const int ts0 = f0 * a.U - a.coff + 64 * part0;
-        const int rel = ts0 >= 0 ? r - 64 * part0 : r - a.coff;      // position inside the source unit (unit 0 starts at t = 0)
-        const bool ok = t < u.te && t >= dil;
-        const unsigned s0 = (unsigned)(j - back - jb) & (RING_SLOTS - 1);
-        const unsigned a0 = ok ? s0 * RING_UNIT_BYTES + (unsigned)(rel >> 4) * 2048u + (unsigned)((rel & 15) + 16 * g) * 16u
-                               : (unsigned)RING_O_ZERO;
-        fr.b[0] = *reinterpret_cast<const bf16x8*>(ring + a0);
-        fr.b[1] = *reinterpret_cast<const bf16x8*>(ring + (ok ? a0 + 1024u : (unsigned)RING_O_ZERO));
-        const float* cr = reinterpret_cast<const float*>(ring + RING_O_COND + slot * RING_COND_BYTES);
+    const int S = NQ + FZ_NL - 1;
+    for (int s = 0; s < S; ++s) {
+        const int q = s - l;                                         // this wave's chunk number in this step
+        if (l == 0) { issue_h0(dp, s + FZ_L0_AHEAD); advance(dp); }  // always one piece per step: the vmcnt below counts on it
+        if (q >= 0 && q < NQ) {
+            if (hh == 0 && cp.c == 0) {                              // two frames ahead: >= 2 NCF - 1 >= 5 younger operations
+                FzPos np = cp; np.c = NCF - 1; advance(np);          // by the time it is read, more than any wait below leaves
+                np.c = NCF - 1; advance(np);
+                issue_cond(np.j, np.b, np.f);
+            }
+            const int fp = first_pos(cp);
+            int fe = (cp.f + 1) * U - coff; fe = fe < a.Tp ? fe : a.Tp;
+            const int t = fp + 16 * cp.c + n;                        // this lane's position in its utterance
+            // ---- fragments of chunk q out of the input level's ring
+            const unsigned sb = in_base + ((unsigned)q & in_mask) * 2048u;
+            bf16x8 fb[4];
+            fb[2] = *reinterpret_cast<const bf16x8*>(lds + sb + hh * 1024 + lane_lds);
+            fb[3] = *reinterpret_cast<const bf16x8*>(lds + sb + (1 - hh) * 1024 + lane_lds);
+            unsigned a0 = FZ_O_ZERO;
+            {
+                const int o = 16 * cp.c + n;                         // offset in the frame image (frame 0: = t)
+                int r = o - dil, dq = -cp.c;                         // source chunk number = q + dq + (r >> 4)
+                bool ok = true;
+                if (cp.f >= 2) { if (r < 0) { r += U; dq -= NCF; } }
+                else if (cp.f == 1) { if (r < 0) { r += U - coff; dq -= NCF; } }     // frame 0's image starts at frame offset coff
+                else ok = r >= 0;                                    // frame 0: zeros in front of the utterance
+                if (ok) a0 = in_base + ((unsigned)(q + dq + (r >> 4)) & in_mask) * 2048u + (unsigned)((r & 15) + 16 * g) * 16u;
+            }
+            fb[0] = *reinterpret_cast<const bf16x8*>(lds + a0);
+            fb[1] = *reinterpret_cast<const bf16x8*>(lds + (a0 == (unsigned)FZ_O_ZERO ? a0 : a0 + 1024u));
+            // ---- epilogue operands
+            const unsigned char* cr = lds + FZ_O_COND + (l * FZ_COND_SLOTS + (cp.j & (FZ_COND_SLOTS - 1))) * 1024 + lc;
+            const unsigned char* kx = lds + FZ_O_CST + l * 1024 + 128 * 4 + lc;
+            float4 czq[2], ccq[2], bzq[2], bcq[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            fr.cz[q] = *reinterpret_cast<const float4*>(cr + 32 * hh + 8 * g + 4 * q);
-            fr.cc[q] = *reinterpret_cast<const float4*>(cr + H + 32 * hh + 8 * g + 4 * q);
+            for (int m = 0; m < 2; ++m) {
+                czq[m] = *reinterpret_cast<const float4*>(cr + 16 * m); ccq[m] = *reinterpret_cast<const float4*>(cr + H * 4 + 16 * m);
+                bzq[m] = *reinterpret_cast<const float4*>(kx + 16 * m); bcq[m] = *reinterpret_cast<const float4*>(kx + H * 4 + 16 * m);
+            }
+            int jo = 16 * cp.c + n + (cp.f == 0 ? coff : 0); jo = jo < 127 ? jo : 127;
+            const float wu = reinterpret_cast<const float*>(lds + FZ_O_WUS)[jo];
+            const float wz = wu * K_SIG, wc = wu * K_TANH;
+            // ---- D[64 rows of this half][16 pos] = bd + Wd . [h(t-dil) ; h(t)]
+            f32x4 ac[4];
+            mfma4_first<false>(ac, A, fb[0], kbd);
+            mfma4_next<1, false, false>(ac, A, fb[1]);
+            mfma4_next<2, false, false>(ac, A, fb[2]);
+            mfma4_next<3, true, false>(ac, A, fb[3]);
+            const u32x4 hpq = __builtin_bit_cast(u32x4, fb[2]);      // own tap-1 fragment: the highway input of these channels
+            unsigned hw[4];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) {
+                    const v2f cz2 = p ? (v2f){czq[m].z, czq[m].w} : (v2f){czq[m].x, czq[m].y};
+                    const v2f cc2 = p ? (v2f){ccq[m].z, ccq[m].w} : (v2f){ccq[m].x, ccq[m].y};
+                    const v2f bz2 = p ? (v2f){bzq[m].z, bzq[m].w} : (v2f){bzq[m].x, bzq[m].y};
+                    const v2f bc2 = p ? (v2f){bcq[m].z, bcq[m].w} : (v2f){bcq[m].x, bcq[m].y};
+                    const v2f wuz2 = {wz, wz}, wuc2 = {wc, wc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+                    const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
+                    const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
+                    const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
+                    const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
+                    const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
+                    const v2f qq = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
+                    const v2f cd = mtwo * qq + one;
+                    const unsigned hpw = hpq[m * 2 + p];
+                    const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
+                    const v2f o = z * (hp - cd) + cd;                                  // (1-z) c + z h
+                    hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
+                }
+            uint4 o0;
+            o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
+            // next level's ring (the fragment image of chunk q) and HBM (chunks of this workgroup's own frames only)
+            if (l + 1 < FZ_NL)
+                *reinterpret_cast<uint4*>(lds + out_base + ((unsigned)q & (FZ_LV_SLOTS - 1)) * 2048u + hh * 1024u + lane_lds) = o0;
+            const bool st_ok = cp.j >= jb && real(cp);
+            const unsigned vo = (st_ok && t < fe) ? lane_row : OOB;  // an out-of-range store is dropped but still counted by vmcnt
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, vo,
+                                                   st_ok ? (unsigned)(cp.b * a.Tp + fp + 16 * cp.c) * (H * 2u) : 0u, 0);
+            advance(cp);
         }
-    };
-
-    Frags cf, nf;
-    read_unit(cu, jb, cf);
-    f32x4 acc[2][4];
-    mfma4_first<false>(acc[0], A, cf.b[0], kbd);
-    mfma4_next<1, false, false>(acc[0], A, cf.b[1]);
-    mfma4_next<2, false, false>(acc[0], A, cf.b[2]);
-    mfma4_next<3, true, false>(acc[0], A, cf.b[3]);
-
-    auto body = [&](const int j, f32x4 (&ac)[4], f32x4 (&an)[4]) __attribute__((always_inline)) {
-        // this wave's piece of unit j+1 (issued RING_AHEAD-1 iterations ago) must have landed before the barrier: behind it
-        // in the queue are one store and RING_AHEAD-2 x (piece + store) - wave 0 also issues a conditioning piece per unit
-        if (w == 0) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + 3 * (RING_AHEAD - 2)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 + 2 * (RING_AHEAD - 2)) : "memory");
+        // what a wave issued two (layer 0: six) steps ago has landed / left; then publish this step's LDS writes
+        if (l == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");                               // no LDS read of the loop may move above the barrier
-        __builtin_amdgcn_sched_barrier(0);
-        bounds(du, j + RING_AHEAD);
-        issue(du, j + RING_AHEAD);                                   // into the slot unit j-2 held (last read an iteration ago)
-        advance(du);
-        read_unit(nu, j + 1, nf);
-        const int t0 = cu.ts + 16 * pr, t = t0 + n;
-        int jj = cu.ts + a.coff - cu.f * a.U + 16 * pr + n;
-        jj = jj < 127 ? jj : 127;
-        const float wu = wus[jj];
-        const float wuz = wu * K_SIG, wuc = wu * K_TANH;
-        unsigned hw[4];
-        const u32x4 hpq = __builtin_bit_cast(u32x4, cf.b[2]);        // own tap-1 fragment: the highway input of these channels
-        auto epi = [&](const int m, const int p) __attribute__((always_inline)) {
-            const v2f cz2 = p ? (v2f){cf.cz[m].z, cf.cz[m].w} : (v2f){cf.cz[m].x, cf.cz[m].y};
-            const v2f cc2 = p ? (v2f){cf.cc[m].z, cf.cc[m].w} : (v2f){cf.cc[m].x, cf.cc[m].y};
-            const v2f bz2 = p ? (v2f){kbxz[m].z, kbxz[m].w} : (v2f){kbxz[m].x, kbxz[m].y};
-            const v2f bc2 = p ? (v2f){kbxc[m].z, kbxc[m].w} : (v2f){kbxc[m].x, kbxc[m].y};
-            const v2f wuz2 = {wuz, wuz}, wuc2 = {wuc, wuc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
-            const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
-            const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
-            const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
-            const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
-            const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
-            const v2f q = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
-            const v2f cd = mtwo * q + one;
-            const unsigned hpw = hpq[m * 2 + p];
-            const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
-            const v2f o = z * (hp - cd) + cd;                                      // (1-z) c + z h
-            hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
-        };
-        mfma4_first<false>(an, A, nf.b[0], kbd);        epi(0, 0);
-        mfma4_next<1, false, false>(an, A, nf.b[1]);    epi(0, 1);
-        mfma4_next<2, false, false>(an, A, nf.b[2]);    epi(1, 0);
-        mfma4_next<3, true, false>(an, A, nf.b[3]);     epi(1, 1);
-        uint4 o0;
-        o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
-        const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h + own : OOB;
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
-        cf = nf; cu = nu;
-        advance(nu); bounds(nu, j + 2);
-    };
-    int j = jb;
-    for (; j + 1 < je; j += 2) { body(j, acc[0], acc[1]); body(j + 1, acc[1], acc[0]); }
-    if (j < je) body(j, acc[0], acc[1]);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // pieces of units past the range are still landing
+        asm volatile("" ::: "memory");                               // no LDS access of the next step may move above the barrier
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // pieces past the range may still be landing
 }
 
 // ---- head: skip (K = L*64) -> relu -> out_1 (128x128) -> relu -> out_2 (<=16 x 128) ----------------
@@ -1221,21 +1220,19 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     const int n_chunks = batch * (int)((Tp + 15) / 16);
     const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
     const int nch = (g.U + 15) / 16;
-#if defined(SWN_RING_LAYER)          // experimental: see bf16_layer_ring_kernel
-    if (g.seg == 1 && g.U >= 32 && nch <= 7) {
-        // LDS-DMA ring, two waves per SIMD (bf16_layer_ring_kernel): one workgroup per CU walks a contiguous range of units
+#if !defined(SWN_OLD_UNITS) && !defined(SWN_HALF_UNITS)
+    if (g.seg == 1 && g.U >= 33 && nch <= 7 && g.L == FZ_NL) {
+        // all six gated layers in one launch (bf16_stack_fused_kernel): one workgroup per CU walks a contiguous range of frames
         const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frames per utterance
-        const int SP = nch > 4 ? 2 : 1;
-        const int n_units = batch * Fu * SP;
-        const int ug = n_units < 256 ? n_units : 256;
+        const int n_fr = batch * Fu;
+        const int ug = n_fr < 256 ? n_fr : 256;
         static bool attr_set = false;
         if (!attr_set) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_layer_ring_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    RING_LDS_BYTES) != hipSuccess) return SWN_E_LAUNCH;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(bf16_stack_fused_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    FZ_LDS_BYTES) != hipSuccess) return SWN_E_LAUNCH;
             attr_set = true;
         }
-        for (int l = 0; l < g.L; ++l)
-            hipLaunchKernelGGL(bf16_layer_ring_kernel, dim3(ug), dim3(512), RING_LDS_BYTES, st, a, l, g.dil[l], n_units, Fu, SP);
+        hipLaunchKernelGGL(bf16_stack_fused_kernel, dim3(ug), dim3(768), FZ_LDS_BYTES, st, a, n_fr, Fu);
     } else
 #endif
 #if defined(SWN_HALF_UNITS)         // experimental: see bf16_layer_half_kernel
