@@ -429,11 +429,7 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
         const unsigned base = (unsigned)(u.b * a.Tp + t0) * (H * 2u) + lane_h;
         const bool ok = t < u.te;
         const unsigned o1 = ok ? base : OOB;
-#ifdef SWN_NOTAP0
-        const unsigned o0 = (ok && t >= dil && dil == 12345) ? base - dil_bytes : OOB;
-#else
         const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
-#endif
         fr.b[0] = buf_ld_bf8(rh, o0); fr.b[1] = buf_ld_bf8(rh, o0 + 64u);
         fr.b[2] = buf_ld_bf8(rh, o1); fr.b[3] = buf_ld_bf8(rh, o1 + 64u);
     };
@@ -486,9 +482,6 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
 #pragma unroll
                 for (int p = 0; p < 2; ++p) {
                     const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[4 + m][2 * p], ac[4 + m][2 * p + 1]};
-#ifdef SWN_NOEPI
-                    { const v2f o = az + acd; hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2)); continue; }
-#endif
                     const v2f pz = (wuz2 * cz2[p] + bz2[p]) * az, pc = (wuc2 * cc2[p] + bc2[p]) * acd;
                     const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
                     const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
@@ -508,11 +501,7 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
             uint4 o0, o1;
             o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
             o1.x = hw[4]; o1.y = hw[5]; o1.z = hw[6]; o1.w = hw[7];
-#ifdef SWN_NOSTORE
-            const unsigned so = (o0.x == 0x12345678u) ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h : OOB;
-#else
             const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h : OOB;
-#endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o1), rn, so + 64u, 0, 0);
         }
@@ -526,229 +515,33 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_units_kernel(const BfArgs a
     for (int j = j0 + js; j < j1; j += js) unit_body(j);
 }
 
-// ---- half-channel variant of the frame-unit layer: TWO waves per SIMD ------------------------------------------------
-// A lone wave issues one vector instruction per 4 cycles where the SIMD could take one per 2 (MI355X_MICROARCH.md, row
-// 'vector-instruction ISSUE cost'), and the units kernel above IS bound by its vector issue (gate epilogue: 50 % of its
-// cycles, the cap of a lone wave; MFMA 22 %, waiting 29 %).  Here a 512-thread workgroup puts two waves on every SIMD:
-// a wave PAIR walks the units of one wave of the kernel above, wave hh of the pair owning channels [32 hh, 32 hh + 32)
-// - the M-tiles {2hh, 2hh+1} (gate) and {4+2hh, 4+2hh+1} (candidate) of the same permuted A image, 64 resident
-// registers instead of 128 - so that one wave's epilogue runs beside its partner's MFMAs and memory waits.  Both waves
-// load all four B fragments of a chunk (the second copy comes out of L1/L2: HBM traffic is unchanged); a lane finishes
-// the 8 channels of its own tap-1 fragment (chan_of: 32 hh + 8 g + 0..7) and stores them as ONE 16-byte piece.
-// The k-steps of a wave are ordered [tap0 lo, tap0 hi, tap1 OWN half, tap1 other half], so the code is the same for
-// both halves and only load offsets differ.  Units are at most 4 chunks (U > 64: two sub-units per frame).
+// ---- 4-tile MFMA helpers of the depth-fused kernel below (a wave owns the 64 rows of one channel half) --------------------
+// EVERY operand in architectural VGPRs: a kernel that names no AccVGPR gets the whole register budget of its occupancy as
+// VGPRs (with any "a" operand hipcc splits it half and half: 84 + 84 at three waves per SIMD).  K-step-major order as in
+// mfma_first / mfma_next above; the tail waits for the MFMA -> VALU hazard.
 #define SWN_MF "v_mfma_f32_16x16x32_bf16 "
-template <bool B_ACC = true, class BT>
-__device__ __forceinline__ void mfma4_first(f32x4 (&acc)[4], const bf16x8 (&A)[4][4], const BT& b, const f32x4 (&c)[4]) {
-#define SWN_MF4F "s_nop 3\n\t" SWN_MF "%0, %4, %8, %9\n\t" SWN_MF "%1, %5, %8, %10\n\t" SWN_MF "%2, %6, %8, %11\n\t" \
-                 SWN_MF "%3, %7, %8, %12"
-    if (B_ACC)
-        asm(SWN_MF4F : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
-            : "a"(A[0][0]), "a"(A[1][0]), "a"(A[2][0]), "a"(A[3][0]), "a"(b), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
-    else
-        asm(SWN_MF4F : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
-            : "a"(A[0][0]), "a"(A[1][0]), "a"(A[2][0]), "a"(A[3][0]), "v"(b), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
-#undef SWN_MF4F
+__device__ __forceinline__ void mfma4v_first(f32x4 (&acc)[4], const bf16x8 (&A)[4][4], const bf16x8& b, const f32x4 (&c)[4]) {
+    asm("s_nop 3\n\t" SWN_MF "%0, %4, %8, %9\n\t" SWN_MF "%1, %5, %8, %10\n\t" SWN_MF "%2, %6, %8, %11\n\t" SWN_MF "%3, %7, %8, %12"
+        : "=&v"(acc[0]), "=&v"(acc[1]), "=&v"(acc[2]), "=&v"(acc[3])
+        : "v"(A[0][0]), "v"(A[1][0]), "v"(A[2][0]), "v"(A[3][0]), "v"(b), "v"(c[0]), "v"(c[1]), "v"(c[2]), "v"(c[3]));
 }
-template <int KS, bool TAIL, bool B_ACC>
-__device__ __forceinline__ void mfma4_next(f32x4 (&acc)[4], const bf16x8 (&A)[4][4], const bf16x8& b) {
+template <int KS, bool TAIL>
+__device__ __forceinline__ void mfma4v_next(f32x4 (&acc)[4], const bf16x8 (&A)[4][4], const bf16x8& b) {
 #define SWN_MF4 SWN_MF "%0, %4, %8, %0\n\t" SWN_MF "%1, %5, %8, %1\n\t" SWN_MF "%2, %6, %8, %2\n\t" SWN_MF "%3, %7, %8, %3"
-#define SWN_MF_OPS(BC) \
-        : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]) \
-        : "a"(A[0][KS]), "a"(A[1][KS]), "a"(A[2][KS]), "a"(A[3][KS]), BC(b)
-    // a k-step is four MFMAs (64 cycles of matrix pipe): the dependent MFMA of the next k-step is three instructions
-    // behind its producer, within the forwarding window of the same opcode; the tail waits for the MFMA -> VALU hazard
-    if (TAIL && B_ACC) asm("s_nop 3\n\t" SWN_MF4 "\n\ts_nop 15" SWN_MF_OPS("a"));
-    else if (TAIL) asm("s_nop 3\n\t" SWN_MF4 "\n\ts_nop 15" SWN_MF_OPS("v"));
-    else if (B_ACC) asm("s_nop 3\n\t" SWN_MF4 SWN_MF_OPS("a"));
-    else asm("s_nop 3\n\t" SWN_MF4 SWN_MF_OPS("v"));
-#undef SWN_MF_OPS
+    if (TAIL) asm("s_nop 3\n\t" SWN_MF4 "\n\ts_nop 15" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+                  : "v"(A[0][KS]), "v"(A[1][KS]), "v"(A[2][KS]), "v"(A[3][KS]), "v"(b));
+    else asm("s_nop 3\n\t" SWN_MF4 : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3])
+             : "v"(A[0][KS]), "v"(A[1][KS]), "v"(A[2][KS]), "v"(A[3][KS]), "v"(b));
 #undef SWN_MF4
 }
 #undef SWN_MF
 
-struct CondHalf { float4 cz[2], cc[2]; };      // hoisted in_x rows of this lane's 8 channels (gate | candidate)
-
-template <int NCH>
-__global__ __launch_bounds__(512, 2) void bf16_layer_half_kernel(const BfArgs a, const int l, const int dil,
-                                                                 const int n_units, const int Fu, const int SP) {
-    static_assert(NCH >= 1 && NCH <= 4, "units of at most four chunks");
-    __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | prescaled bx[128] of this layer
-    __shared__ float wus[128];                                       // upsampler taps (U <= 112)
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int hh = w & 1, pr = w >> 1;                               // channel half, pair index inside the workgroup
-    const int n = lane & 15, g = lane >> 4;
-    if (tid < 256)
-        cst[tid] = tid < 128 ? a.P[a.y.bd + (size_t)l * 128 + tid]
-                             : a.P[a.y.bx + (size_t)l * 128 + tid - 128] * (tid < 192 ? K_SIG : K_TANH);
-    else if (tid < 384) wus[tid - 256] = tid - 256 < a.U ? a.P[a.y.wup + tid - 256] : 0.f;
-    bf16x8 A[4][4];
-    {
-        const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int mt = (t >> 1) * 4 + 2 * hh + (t & 1);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const int kk = ks < 2 ? ks : (ks == 2 ? 2 + hh : 3 - hh);       // own tap-1 half first
-                A[t][ks] = src[(mt * 4 + kk) * 64 + lane];
-            }
-        }
-    }
-    __syncthreads();
-    f32x4 kbd[4];
-    float4 kbxz[2], kbxc[2];
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const int ch = 32 * hh + 8 * g + 4 * m;                      // = chan_of(2 hh + m, g, 0)
-        kbd[m] = *reinterpret_cast<const f32x4*>(cst + ch);
-        kbd[2 + m] = *reinterpret_cast<const f32x4*>(cst + H + ch);
-        kbxz[m] = *reinterpret_cast<const float4*>(cst + 128 + ch);
-        kbxc[m] = *reinterpret_cast<const float4*>(cst + 128 + H + ch);
-    }
-    const size_t lstride = (size_t)a.B * a.Tp * H;
-    const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
-    const __amdgpu_buffer_rsrc_t rn = make_rsrc(a.hs + (size_t)(l + 1) * lstride, lstride * 2);
-    const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
-    const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u;
-    const unsigned own = 64u * (unsigned)hh, oth = 64u - own;        // byte offsets of the own / other channel half in a row
-    const unsigned lane_c = (unsigned)(32 * hh + 8 * g) * 4u;
-    const unsigned dil_bytes = (unsigned)dil * H * 2u;
-
-    const int js = gridDim.x * 4, j0 = blockIdx.x * 4 + pr, j1 = n_units;
-    if (j0 >= j1) return;
-
-    auto unit_of = [&](int j) -> Unit {                              // scalar
-        Unit u;
-        const bool ok = j < j1;
-        const int jc = ok ? j : j1 - 1;
-        const int fs = jc / SP, part = jc - fs * SP;
-        u.b = fs / Fu; u.f = fs - u.b * Fu;
-        const int s = u.f * a.U - a.coff, e = s + a.U;
-        const int ps = s + part * (16 * NCH), pe = ps + 16 * NCH < e ? ps + 16 * NCH : e;
-        u.ts = ps > 0 ? ps : 0;
-        u.te = ok ? (pe < a.Tp ? pe : a.Tp) : 0;
-        if (u.te < u.ts) u.te = u.ts;
-        u.jj0 = u.ts - s;
-        return u;
-    };
-    auto fetch_b = [&](const Unit& u, int i, BFrag& fr) {
-        const int t0 = u.ts + 16 * i, t = t0 + n;
-        const unsigned base = (unsigned)(u.b * a.Tp + t0) * (H * 2u) + lane_h;
-        const bool ok = t < u.te;
-        const unsigned o1 = ok ? base : OOB;
-#ifdef SWN_NOTAP0
-        const unsigned o0 = (ok && t >= dil && dil == 12345) ? base - dil_bytes : OOB;
-#else
-        const unsigned o0 = (ok && t >= dil) ? base - dil_bytes : OOB;
-#endif
-        fr.b[0] = buf_ld_bf8(rh, o0); fr.b[1] = buf_ld_bf8(rh, o0 + 64u);
-        fr.b[2] = buf_ld_bf8(rh, o1 + own); fr.b[3] = buf_ld_bf8(rh, o1 + oth);
-    };
-    auto fetch_rows = [&](const Unit& u, CondHalf& r) {
-        const int fc = u.f < a.Tf - 1 ? u.f : a.Tf - 1;
-        const unsigned off = (unsigned)((u.b * a.Tf + fc) * a.N + l * 128) * 4u + lane_c;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            r.cz[q] = buf_ld_f4(rc, off + (unsigned)(4 * q) * 4u);
-            r.cc[q] = buf_ld_f4(rc, off + (unsigned)(H + 4 * q) * 4u);
-        }
-    };
-
-    Unit cu = unit_of(j0), nu = unit_of(j0 + js);
-    CondHalf cur;
-    fetch_rows(cu, cur);
-    BFrag ring[NCH];
-#pragma unroll
-    for (int i = 0; i < NCH - 1; ++i) fetch_b(cu, i, ring[i]);
-    if (NCH == 1) fetch_b(cu, 0, ring[0]);
-    f32x4 acc[2][4];
-    mfma4_first(acc[0], A, ring[0].b[0], kbd);
-    mfma4_next<1, false, true>(acc[0], A, ring[0].b[1]);
-    mfma4_next<2, false, false>(acc[0], A, ring[0].b[2]);
-    mfma4_next<3, true, false>(acc[0], A, ring[0].b[3]);
-
-    auto unit_body = [&](const int j) __attribute__((always_inline)) {
-        CondHalf nxt;
-        fetch_rows(nu, nxt);
-#pragma unroll
-        for (int i = 0; i < NCH; ++i) {
-            if (NCH > 1) {
-                if (i == 0) fetch_b(cu, NCH - 1, ring[NCH - 1]);     // slot freed by the previous unit's last chunk
-                else fetch_b(nu, i - 1, ring[i - 1]);                // slot freed by this unit's chunk i-1
-            }
-            const int t0 = cu.ts + 16 * i, t = t0 + n;
-            const float wu = wus[cu.jj0 + 16 * i + n];
-            const float wuz = wu * K_SIG, wuc = wu * K_TANH;
-            f32x4 (&ac)[4] = acc[i & 1];
-            f32x4 (&an)[4] = acc[(i + 1) & 1];
-            const BFrag& cb = ring[i];
-            unsigned hw[4];                                          // 8 finished channels, two bf16 per word
-            const u32x4 hpq = __builtin_bit_cast(u32x4, cb.b[2]);    // own tap-1 fragment: the highway input of these channels
-            auto epi = [&](const int m, const int p) __attribute__((always_inline)) {
-                const v2f cz2 = p ? (v2f){cur.cz[m].z, cur.cz[m].w} : (v2f){cur.cz[m].x, cur.cz[m].y};
-                const v2f cc2 = p ? (v2f){cur.cc[m].z, cur.cc[m].w} : (v2f){cur.cc[m].x, cur.cc[m].y};
-                const v2f bz2 = p ? (v2f){kbxz[m].z, kbxz[m].w} : (v2f){kbxz[m].x, kbxz[m].y};
-                const v2f bc2 = p ? (v2f){kbxc[m].z, kbxc[m].w} : (v2f){kbxc[m].x, kbxc[m].y};
-                const v2f wuz2 = {wuz, wuz}, wuc2 = {wuc, wuc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
-                const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
-#ifdef SWN_NOEPI
-                { const v2f o = az + acd; hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2)); return; }
-#endif
-                const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
-                const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
-                const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
-                const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
-                const v2f q = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
-                const v2f cd = mtwo * q + one;
-                const unsigned hpw = hpq[m * 2 + p];
-                const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
-                const v2f o = z * (hp - cd) + cd;                                      // (1-z) c + z h
-                hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
-            };
-            if (NCH == 1) {
-                // one-chunk units: the next chunk is the next unit's, its fragments were requested a unit ago
-                epi(0, 0); epi(0, 1); epi(1, 0); epi(1, 1);
-            } else {
-                const BFrag& nb = ring[(i + 1) % NCH];               // i == NCH-1: slot 0 already holds (next unit, 0)
-                mfma4_first(an, A, nb.b[0], kbd);               epi(0, 0);
-                mfma4_next<1, false, true>(an, A, nb.b[1]);     epi(0, 1);
-                mfma4_next<2, false, false>(an, A, nb.b[2]);    epi(1, 0);
-                mfma4_next<3, true, false>(an, A, nb.b[3]);     epi(1, 1);
-            }
-            uint4 o0;
-            o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
-#ifdef SWN_NOSTORE
-            const unsigned so = (o0.x == 0x12345678u) ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h + own : OOB;
-#else
-            const unsigned so = t < cu.te ? (unsigned)(cu.b * a.Tp + t0) * (H * 2u) + lane_h + own : OOB;
-#endif
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, so, 0, 0);
-        }
-        if (NCH == 1) {
-            fetch_b(nu, 0, ring[0]);
-            mfma4_first(acc[0], A, ring[0].b[0], kbd);
-            mfma4_next<1, false, true>(acc[0], A, ring[0].b[1]);
-            mfma4_next<2, false, false>(acc[0], A, ring[0].b[2]);
-            mfma4_next<3, true, false>(acc[0], A, ring[0].b[3]);
-        } else if (NCH & 1) {                                        // odd chunk count: realign the accumulator parity
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[0][mt] = acc[1][mt];
-        }
-        cur = nxt; cu = nu; nu = unit_of(j + 2 * js);
-    };
-    unit_body(j0);
-    for (int j = j0 + js; j < j1; j += js) unit_body(j);
-}
-
 // ---- depth-fused gated stack: all six layers of a position range in ONE launch ---------------------------------------------
 // Per-layer launches move every hidden state through HBM twice (written by layer l, read by layer l+1) and pay a launch, a
-// weight fetch per wave and a drain per layer - at BASELINE cfg4's own 8 x 16 500 that fixed part is most of a 16 us launch.
-// What bounds the per-layer kernels above is not arithmetic either (without their epilogue they run 8 % faster, without their
-// stores 9 %): it is the unique bytes they keep in flight.  Here a 768-thread workgroup (one per CU) walks a CONTIGUOUS range of
-// conditioning frames; wave (l, hh) owns layer l and the channels [32 hh, 32 hh + 32) (64 resident A registers, the M-tiles of
-// bf16_layer_half_kernel), and the twelve waves step through the chunk sequence in lock-step, layer l one chunk behind layer l-1:
+// 32 KB weight fetch per wave and a drain per layer - at BASELINE cfg4's own 8 x 16 500 that fixed part is a third of a 16 us
+// launch.  Here a 768-thread workgroup (one per CU) walks a CONTIGUOUS range of conditioning frames; wave (l, hh) owns layer l
+// and the channels [32 hh, 32 hh + 32) (the M-tiles {2hh, 2hh+1} gate / {4+2hh, 4+2hh+1} candidate of the permuted A image:
+// 64 resident registers), and the twelve waves step through the chunk sequence in lock-step, layer l one chunk behind layer l-1:
 //   * h0 arrives by LDS-DMA (`buffer_load_dwordx4 ... lds`, 8 chunks ahead, each 1-KiB piece laid down in MFMA B-fragment
 //     order: lane (n, g) fetches position n, channels 8g.. of its half - the piece IS the fragment image);
 //   * a layer's output chunk-half is ONE ds_write_b128 per lane into the next level's 8-chunk LDS ring - the same fragment
@@ -758,12 +551,17 @@ __global__ __launch_bounds__(512, 2) void bf16_layer_half_kernel(const BfArgs a,
 //     (h0) instead of six times;
 //   * one workgroup barrier per step; LDS-DMA data is ordered for its readers by the issuer's counted vmcnt + that barrier
 //     (cdna_hip_programming.md 5 "Pipelining across barriers"; the DMA statements are asm, so hipcc adds no waits of its own);
-//   * a range starts FZ_HALO chunks early (the stack reaches 63 positions back); halo chunks are computed, not stored.
+//   * a range starts a few chunks early (the stack reaches 63 positions back); halo chunks are computed, not stored.
 // Chunks are frame-aligned (NCF = ceil(U / 16) per conditioning frame, the last one ragged), so the hoisted in_x row is
-// uniform per chunk.  Frames 0 and 1 of an utterance (zero padding in front, frame 0 shorter by `coff`) take a general path.
-constexpr int FZ_L0_SLOTS = 16, FZ_L0_AHEAD = 8, FZ_LV_SLOTS = 8, FZ_COND_SLOTS = 4, FZ_HALO = 5, FZ_NL = 6;
+// uniform per chunk.  Frames 0 and 1 of an utterance (zero padding in front, frame 0 shorter by `coff`) change two scalars.
+// Measured: the six layers 96 -> 77 us at 8 x 16 500, 451 -> 460 us at 64 x 16 500.  What was tried on top and
+// measured no better: two half-steps per chunk with consecutive layers in opposite phases (+8 %), MFMAs of chunk q+1 between
+// the epilogue quarters of chunk q inside a wave (+7..13 %: six more LDS reads per step), a branch-free step loop (+-0);
+// removing the barrier changes nothing, removing the MFMAs or the epilogue a quarter each: a step is ~3 500 cycles of twelve
+// waves' vector-instruction issue (146 VALU + 70 SALU per wave and step), not a wait.
+constexpr int FZ_L0_SLOTS = 16, FZ_L0_AHEAD = 8, FZ_LV_SLOTS = 8, FZ_COND_SLOTS = 4, FZ_NL = 6;
 constexpr int FZ_O_LV = FZ_L0_SLOTS * 2048;                                  // levels 1..5 behind level 0
-constexpr int FZ_O_COND = FZ_O_LV + (FZ_NL - 1) * FZ_LV_SLOTS * 2048;        // [layer][frame & 3][1 KB piece]
+constexpr int FZ_O_COND = FZ_O_LV + FZ_NL * FZ_LV_SLOTS * 2048;              // [layer][frame & 3][1 KB piece]
 constexpr int FZ_O_CST = FZ_O_COND + FZ_NL * FZ_COND_SLOTS * 1024;           // [layer][bd 128 | prescaled bx 128] floats
 constexpr int FZ_O_WUS = FZ_O_CST + FZ_NL * 256 * 4;                         // upsampler taps, 128 floats
 constexpr int FZ_O_ZERO = FZ_O_WUS + 128 * 4;                                // 16 zero bytes (tap-0 reads before t = 0)
@@ -773,8 +571,10 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 // one 1-KiB LDS-DMA piece: lane i's 16 bytes land at lds_base + 16 i; voff (per lane; the range check is on it) + soff =
 // byte offset into the buffer, out of range: zeros.  M0 carries the LDS base and is written in the statement that reads it.
 __device__ __forceinline__ void dma_piece(const v4i rsrc, unsigned voff, unsigned soff, unsigned lds_base) {
+    // (the two scalar operands are wave-uniform by construction; readfirstlane makes that visible to the register allocator)
     asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
-                 :: "v"(voff), "s"(rsrc), "s"(soff), "s"(lds_base) : "memory");
+                 :: "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)soff)),
+                    "s"(__builtin_amdgcn_readfirstlane((int)lds_base)) : "memory");
 }
 __device__ __forceinline__ v4i raw_rsrc(const void* p, size_t bytes) {
     const unsigned long long a = reinterpret_cast<unsigned long long>(p);
@@ -803,7 +603,7 @@ __global__ __launch_bounds__(768) void bf16_stack_fused_kernel(const BfArgs a, c
     if (tid < 128) reinterpret_cast<float*>(lds + FZ_O_WUS)[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
     if (tid < 4) reinterpret_cast<unsigned*>(lds + FZ_O_ZERO)[tid] = 0u;
     // the rings start as zeros: the first chunks read tap-0 slots no producer has written (nothing real depends on them)
-    for (int e = tid; e < FZ_O_COND / 16; e += 768) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
+    for (int e = tid; e < FZ_O_CST / 16; e += 768) reinterpret_cast<uint4*>(lds)[e] = make_uint4(0u, 0u, 0u, 0u);
     bf16x8 A[4][4];
     {
         const bf16x8* src = reinterpret_cast<const bf16x8*>(a.wbf + a.off_wd) + (size_t)l * 8 * 4 * 64;
@@ -834,17 +634,21 @@ __global__ __launch_bounds__(768) void bf16_stack_fused_kernel(const BfArgs a, c
     const unsigned cond_voff = lane < 32 ? (unsigned)lane * 16u : OOB;
     const unsigned in_base = l == 0 ? 0u : (unsigned)(FZ_O_LV + (l - 1) * FZ_LV_SLOTS * 2048);   // ring of this layer's input level
     const unsigned in_mask = l == 0 ? FZ_L0_SLOTS - 1 : FZ_LV_SLOTS - 1;
-    const unsigned out_base = (unsigned)(FZ_O_LV + l * FZ_LV_SLOTS * 2048);                       // l < 5 only
+    const unsigned out_base = (unsigned)(FZ_O_LV + l * FZ_LV_SLOTS * 2048);                       // (layer 5: a spare ring)
 
-    // this workgroup's contiguous range of frames, entered FZ_HALO chunks early
+    // this workgroup's contiguous range of frames, entered `halo` chunks early
     const int G = gridDim.x, k = blockIdx.x;
     const int jb = (int)((long)n_frames_all * k / G), je = (int)((long)n_frames_all * (k + 1) / G);
     if (jb >= je) return;
-    const int hf = (FZ_HALO + NCF - 1) / NCF;                        // frames the halo reaches back
-    const int NQ = FZ_HALO + (je - jb) * NCF;                        // chunks every layer walks; chunk number 0 is (jb - hf, hf NCF - FZ_HALO)
+    // halo: the chunks in front of frame jb that hold the 63 positions the six layers reach back (the last chunk of a frame
+    // may hold as little as one position)
+    int halo = 0;
+    for (int pos = 0, c = NCF - 1; pos < 64; ++halo) { pos += (U - 16 * c) < 16 ? (U - 16 * c) : 16; c = c == 0 ? NCF - 1 : c - 1; }
+    const int hf = (halo + NCF - 1) / NCF;                           // frames the halo reaches back
+    const int NQ = halo + (je - jb) * NCF;                           // chunks every layer walks; chunk number 0 is (jb - hf, hf NCF - halo)
     auto pos_at = [&](int q) -> FzPos {                              // scalar, with divisions: seeds a walker
         FzPos p;
-        const int qq = q + hf * NCF - FZ_HALO;                       // chunks since the start of frame jb - hf
+        const int qq = q + hf * NCF - halo;                          // chunks since the start of frame jb - hf
         p.j = jb - hf + qq / NCF; p.c = qq - (qq / NCF) * NCF;
         const int jc = p.j < 0 ? 0 : p.j;
         p.b = jc / Fu; p.f = jc - p.b * Fu;
@@ -874,98 +678,114 @@ __global__ __launch_bounds__(768) void bf16_stack_fused_kernel(const BfArgs a, c
     if (l == 0) {
         for (int q = 0; q < FZ_L0_AHEAD; ++q) { issue_h0(dp, q); advance(dp); }
     }
-    if (hh == 0) {                                                   // rows of the first two frames; the loop stays two frames ahead
-        issue_cond(cp.j, cp.b, cp.f);
+    if (hh == 0) {                                                   // rows of the first three frames: the loop issues frame j + 2
+        issue_cond(cp.j, cp.b, cp.f);                                // when it enters frame j, and it may enter its first frame mid-way
         FzPos np = cp; np.c = NCF - 1; advance(np);                  // first chunk of the next frame
+        issue_cond(np.j, np.b, np.f);
+        np.c = NCF - 1; advance(np);
         issue_cond(np.j, np.b, np.f);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
+    // The step loop is kept free of scalar branches (a taken s_cbranch costs a wave more than the four MFMAs of a k-step):
+    // every wave runs the whole body in every step - before its first and after its last chunk on whatever the rings hold,
+    // with the stores switched off (nothing real reads what such a step writes: the slot it writes is rewritten by the real
+    // producer before its reader arrives, or its readers are done) - and everything that depends on the frame only is a
+    // scalar refreshed when the walker enters a frame.
+    int fp = 0, fe = 0, uprev = U, gpos = 0, cslot = 0;              // first / end position in the utterance, previous frame's image length, b*Tp + fp
+    bool zero_front = false, st_frame = false;
+    auto enter_frame = [&]() {
+        fp = cp.f * U - coff; fp = fp > 0 ? fp : 0;
+        fe = (cp.f + 1) * U - coff; fe = fe < a.Tp ? fe : a.Tp;
+        uprev = cp.f == 1 ? U - coff : U;                            // frame 0's image starts at frame offset coff
+        zero_front = cp.f == 0;                                      // zeros in front of the utterance
+        gpos = cp.b * a.Tp + fp;
+        cslot = cp.j & (FZ_COND_SLOTS - 1);
+        st_frame = cp.j >= jb && cp.j >= 0 && cp.j < n_frames_all;   // halo chunks are computed, not stored
+    };
+    enter_frame();
+    const unsigned voob = OOB;
     const int S = NQ + FZ_NL - 1;
     for (int s = 0; s < S; ++s) {
         const int q = s - l;                                         // this wave's chunk number in this step
+        const bool live = q >= 0 && q < NQ;
         if (l == 0) { issue_h0(dp, s + FZ_L0_AHEAD); advance(dp); }  // always one piece per step: the vmcnt below counts on it
-        if (q >= 0 && q < NQ) {
-            if (hh == 0 && cp.c == 0) {                              // two frames ahead: >= 2 NCF - 1 >= 5 younger operations
-                FzPos np = cp; np.c = NCF - 1; advance(np);          // by the time it is read, more than any wait below leaves
-                np.c = NCF - 1; advance(np);
-                issue_cond(np.j, np.b, np.f);
-            }
-            const int fp = first_pos(cp);
-            int fe = (cp.f + 1) * U - coff; fe = fe < a.Tp ? fe : a.Tp;
-            const int t = fp + 16 * cp.c + n;                        // this lane's position in its utterance
-            // ---- fragments of chunk q out of the input level's ring
-            const unsigned sb = in_base + ((unsigned)q & in_mask) * 2048u;
-            bf16x8 fb[4];
-            fb[2] = *reinterpret_cast<const bf16x8*>(lds + sb + hh * 1024 + lane_lds);
-            fb[3] = *reinterpret_cast<const bf16x8*>(lds + sb + (1 - hh) * 1024 + lane_lds);
-            unsigned a0 = FZ_O_ZERO;
-            {
-                const int o = 16 * cp.c + n;                         // offset in the frame image (frame 0: = t)
-                int r = o - dil, dq = -cp.c;                         // source chunk number = q + dq + (r >> 4)
-                bool ok = true;
-                if (cp.f >= 2) { if (r < 0) { r += U; dq -= NCF; } }
-                else if (cp.f == 1) { if (r < 0) { r += U - coff; dq -= NCF; } }     // frame 0's image starts at frame offset coff
-                else ok = r >= 0;                                    // frame 0: zeros in front of the utterance
-                if (ok) a0 = in_base + ((unsigned)(q + dq + (r >> 4)) & in_mask) * 2048u + (unsigned)((r & 15) + 16 * g) * 16u;
-            }
-            fb[0] = *reinterpret_cast<const bf16x8*>(lds + a0);
-            fb[1] = *reinterpret_cast<const bf16x8*>(lds + (a0 == (unsigned)FZ_O_ZERO ? a0 : a0 + 1024u));
-            // ---- epilogue operands
-            const unsigned char* cr = lds + FZ_O_COND + (l * FZ_COND_SLOTS + (cp.j & (FZ_COND_SLOTS - 1))) * 1024 + lc;
-            const unsigned char* kx = lds + FZ_O_CST + l * 1024 + 128 * 4 + lc;
-            float4 czq[2], ccq[2], bzq[2], bcq[2];
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                czq[m] = *reinterpret_cast<const float4*>(cr + 16 * m); ccq[m] = *reinterpret_cast<const float4*>(cr + H * 4 + 16 * m);
-                bzq[m] = *reinterpret_cast<const float4*>(kx + 16 * m); bcq[m] = *reinterpret_cast<const float4*>(kx + H * 4 + 16 * m);
-            }
-            int jo = 16 * cp.c + n + (cp.f == 0 ? coff : 0); jo = jo < 127 ? jo : 127;
-            const float wu = reinterpret_cast<const float*>(lds + FZ_O_WUS)[jo];
-            const float wz = wu * K_SIG, wc = wu * K_TANH;
-            // ---- D[64 rows of this half][16 pos] = bd + Wd . [h(t-dil) ; h(t)]
-            f32x4 ac[4];
-            mfma4_first<false>(ac, A, fb[0], kbd);
-            mfma4_next<1, false, false>(ac, A, fb[1]);
-            mfma4_next<2, false, false>(ac, A, fb[2]);
-            mfma4_next<3, true, false>(ac, A, fb[3]);
-            const u32x4 hpq = __builtin_bit_cast(u32x4, fb[2]);      // own tap-1 fragment: the highway input of these channels
-            unsigned hw[4];
-#pragma unroll
-            for (int m = 0; m < 2; ++m)
-#pragma unroll
-                for (int p = 0; p < 2; ++p) {
-                    const v2f cz2 = p ? (v2f){czq[m].z, czq[m].w} : (v2f){czq[m].x, czq[m].y};
-                    const v2f cc2 = p ? (v2f){ccq[m].z, ccq[m].w} : (v2f){ccq[m].x, ccq[m].y};
-                    const v2f bz2 = p ? (v2f){bzq[m].z, bzq[m].w} : (v2f){bzq[m].x, bzq[m].y};
-                    const v2f bc2 = p ? (v2f){bcq[m].z, bcq[m].w} : (v2f){bcq[m].x, bcq[m].y};
-                    const v2f wuz2 = {wz, wz}, wuc2 = {wc, wc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
-                    const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
-                    const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
-                    const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
-                    const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
-                    const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
-                    const v2f qq = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
-                    const v2f cd = mtwo * qq + one;
-                    const unsigned hpw = hpq[m * 2 + p];
-                    const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
-                    const v2f o = z * (hp - cd) + cd;                                  // (1-z) c + z h
-                    hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
-                }
-            uint4 o0;
-            o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
-            // next level's ring (the fragment image of chunk q) and HBM (chunks of this workgroup's own frames only)
-            if (l + 1 < FZ_NL)
-                *reinterpret_cast<uint4*>(lds + out_base + ((unsigned)q & (FZ_LV_SLOTS - 1)) * 2048u + hh * 1024u + lane_lds) = o0;
-            const bool st_ok = cp.j >= jb && real(cp);
-            const unsigned vo = (st_ok && t < fe) ? lane_row : OOB;  // an out-of-range store is dropped but still counted by vmcnt
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, vo,
-                                                   st_ok ? (unsigned)(cp.b * a.Tp + fp + 16 * cp.c) * (H * 2u) : 0u, 0);
-            advance(cp);
+        if (hh == 0 && cp.c == 0 && live) {                          // two frames ahead: >= 2 NCF - 1 >= 5 younger operations by the
+            FzPos np = cp; np.c = NCF - 1; advance(np);              // time it is read, more than any wait below leaves
+            np.c = NCF - 1; advance(np);
+            issue_cond(np.j, np.b, np.f);
         }
-        // what a wave issued two (layer 0: six) steps ago has landed / left; then publish this step's LDS writes
+        // ---- fragments of chunk q out of the input level's ring
+        const unsigned sb = in_base + ((unsigned)q & in_mask) * 2048u;
+        bf16x8 fb[4];
+        fb[2] = *reinterpret_cast<const bf16x8*>(lds + sb + hh * 1024 + lane_lds);
+        fb[3] = *reinterpret_cast<const bf16x8*>(lds + sb + (1 - hh) * 1024 + lane_lds);
+        const int r0 = 16 * cp.c + n - dil;                          // offset in the frame image of the tap-0 position
+        const bool neg = r0 < 0;
+        const int r = neg ? r0 + uprev : r0;                         // ... in the previous frame's image
+        const int qs = q - cp.c + (r >> 4) - (neg ? NCF : 0);        // its chunk number
+        const bool zf = neg && zero_front;
+        const unsigned a0 = zf ? (unsigned)FZ_O_ZERO
+                               : in_base + ((unsigned)qs & in_mask) * 2048u + (unsigned)(r & 15) * 16u + (unsigned)(16 * g) * 16u;
+        fb[0] = *reinterpret_cast<const bf16x8*>(lds + a0);
+        fb[1] = *reinterpret_cast<const bf16x8*>(lds + (zf ? a0 : a0 + 1024u));
+        // ---- epilogue operands
+        const unsigned char* cr = lds + FZ_O_COND + (l * FZ_COND_SLOTS + cslot) * 1024 + lc;
+        const unsigned char* kx = lds + FZ_O_CST + l * 1024 + 128 * 4 + lc;
+        float4 czq[2], ccq[2], bzq[2], bcq[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            czq[m] = *reinterpret_cast<const float4*>(cr + 16 * m); ccq[m] = *reinterpret_cast<const float4*>(cr + H * 4 + 16 * m);
+            bzq[m] = *reinterpret_cast<const float4*>(kx + 16 * m); bcq[m] = *reinterpret_cast<const float4*>(kx + H * 4 + 16 * m);
+        }
+        int jo = 16 * cp.c + n + (zero_front ? coff : 0); jo = jo < 127 ? jo : 127;
+        const float wu = reinterpret_cast<const float*>(lds + FZ_O_WUS)[jo];
+        const float wz = wu * K_SIG, wc = wu * K_TANH;
+        // ---- D[64 rows of this half][16 pos] = bd + Wd . [h(t-dil) ; h(t)]
+        f32x4 ac[4];
+        mfma4v_first(ac, A, fb[0], kbd);
+        mfma4v_next<1, false>(ac, A, fb[1]);
+        mfma4v_next<2, false>(ac, A, fb[2]);
+        mfma4v_next<3, true>(ac, A, fb[3]);
+        const u32x4 hpq = __builtin_bit_cast(u32x4, fb[2]);          // own tap-1 fragment: the highway input of these channels
+        unsigned hw[4];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                const v2f cz2 = p ? (v2f){czq[m].z, czq[m].w} : (v2f){czq[m].x, czq[m].y};
+                const v2f cc2 = p ? (v2f){ccq[m].z, ccq[m].w} : (v2f){ccq[m].x, ccq[m].y};
+                const v2f bz2 = p ? (v2f){bzq[m].z, bzq[m].w} : (v2f){bzq[m].x, bzq[m].y};
+                const v2f bc2 = p ? (v2f){bcq[m].z, bcq[m].w} : (v2f){bcq[m].x, bcq[m].y};
+                const v2f wuz2 = {wz, wz}, wuc2 = {wc, wc}, one = {1.f, 1.f}, mtwo = {-2.f, -2.f};
+                const v2f az = {ac[m][2 * p], ac[m][2 * p + 1]}, acd = {ac[2 + m][2 * p], ac[2 + m][2 * p + 1]};
+                const v2f pz = (wuz2 * cz2 + bz2) * az, pc = (wuc2 * cc2 + bc2) * acd;
+                const v2f dz = (v2f){__builtin_amdgcn_exp2f(pz.x), __builtin_amdgcn_exp2f(pz.y)} + one;
+                const v2f dc = (v2f){__builtin_amdgcn_exp2f(pc.x), __builtin_amdgcn_exp2f(pc.y)} + one;
+                const v2f z = {__builtin_amdgcn_rcpf(dz.x), __builtin_amdgcn_rcpf(dz.y)};
+                const v2f qq = {__builtin_amdgcn_rcpf(dc.x), __builtin_amdgcn_rcpf(dc.y)};
+                const v2f cd = mtwo * qq + one;
+                const unsigned hpw = hpq[m * 2 + p];
+                const v2f hp = {__builtin_bit_cast(float, hpw << 16), __builtin_bit_cast(float, hpw & 0xffff0000u)};
+                const v2f o = z * (hp - cd) + cd;                                      // (1-z) c + z h
+                hw[m * 2 + p] = __builtin_bit_cast(unsigned, __builtin_convertvector(o, bf16x2));
+            }
+        uint4 o0;
+        o0.x = hw[0]; o0.y = hw[1]; o0.z = hw[2]; o0.w = hw[3];
+        // next level's ring (the fragment image of chunk q; the last layer's writes land in a spare ring nobody reads) and HBM
+        *reinterpret_cast<uint4*>(lds + out_base + ((unsigned)q & (FZ_LV_SLOTS - 1)) * 2048u + hh * 1024u + lane_lds) = o0;
+        const int t = fp + 16 * cp.c + n;                            // this lane's position in its utterance
+        const bool st = st_frame && live;
+        const unsigned vo = (st && t < fe) ? lane_row : voob;        // an out-of-range store is dropped, but vmcnt counts it
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o0), rn, vo, st ? (unsigned)(gpos + 16 * cp.c) * (H * 2u) : 0u, 0);
+        if (live) {
+            const int jprev = cp.j;
+            advance(cp);
+            if (cp.j != jprev) enter_frame();
+        }
+        // what a wave issued two (layer 0: six) operations ago has landed / left; then publish this step's LDS writes
         if (l == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1220,7 +1040,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     const int n_chunks = batch * (int)((Tp + 15) / 16);
     const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
     const int nch = (g.U + 15) / 16;
-#if !defined(SWN_OLD_UNITS) && !defined(SWN_HALF_UNITS)
+#if !defined(SWN_OLD_UNITS)           // diagnostic builds only: the per-layer launches for A/B timing
     if (g.seg == 1 && g.U >= 33 && nch <= 7 && g.L == FZ_NL) {
         // all six gated layers in one launch (bf16_stack_fused_kernel): one workgroup per CU walks a contiguous range of frames
         const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frames per utterance
@@ -1233,23 +1053,6 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
             attr_set = true;
         }
         hipLaunchKernelGGL(bf16_stack_fused_kernel, dim3(ug), dim3(768), FZ_LDS_BYTES, st, a, n_fr, Fu);
-    } else
-#endif
-#if defined(SWN_HALF_UNITS)         // experimental: see bf16_layer_half_kernel
-    if (g.seg == 1 && g.U >= 16 && nch <= 7) {
-        // two waves per SIMD, a wave pair per unit (bf16_layer_half_kernel): units of at most four chunks
-        const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frames per utterance
-        const int SP = nch > 4 ? 2 : 1, NCH = (nch + SP - 1) / SP;
-        const int n_units = batch * Fu * SP;
-        const int ug = (n_units + 3) / 4 < 256 ? (n_units + 3) / 4 : 256;       // one 512-thread workgroup per CU
-        for (int l = 0; l < g.L; ++l) {
-            switch (NCH) {
-                case 1: hipLaunchKernelGGL(bf16_layer_half_kernel<1>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
-                case 2: hipLaunchKernelGGL(bf16_layer_half_kernel<2>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
-                case 3: hipLaunchKernelGGL(bf16_layer_half_kernel<3>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
-                default: hipLaunchKernelGGL(bf16_layer_half_kernel<4>, dim3(ug), dim3(512), 0, st, a, l, g.dil[l], n_units, Fu, SP); break;
-            }
-        }
     } else
 #endif
     if (g.seg == 1 && g.U >= 16 && nch <= 7) {

@@ -103,3 +103,25 @@ def test_module_opt_in_bf16_forward(gpu_ok):
         assert x.shape == y.shape
         assert float((x - y).abs().max()) <= 5e-3 * max(1.0, float(y.abs().max()))
     assert not torch.equal(out[0], ref[0])
+
+
+@pytest.mark.parametrize("U", [33, 48, 64, 65, 80, 96, 110, 112])
+@pytest.mark.parametrize("B,Tf", [(1, 2), (3, 7), (2, 150)])
+def test_depth_fused_stack_over_upsampling_factors_and_range_cuts(gpu_ok, U, B, Tf):
+    """bf16_stack_fused_kernel (all six layers in one launch, LDS rings between the layers) against the fp32 parity kernels:
+    3 .. 7 chunks per conditioning frame (ragged last chunk, U a multiple of 16 and not), frame 0 / frame 1 of an utterance
+    (zero padding in front, the `coff` shift), utterance boundaries inside a workgroup's range, ranges of one frame (more
+    workgroups than a halo is long) and of several.  Tolerance: the bf16 path's 3e-3 of the output scale."""
+    import dataclasses
+    cfg = dataclasses.replace(C.bl6_laplace(1, 0), upsampling_factor=U)
+    sd = synth_state_dict(cfg, seed=2, flavor="trained")
+    net = HipNet.from_state_dict(cfg, sd, "cuda:0")
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf))
+    T = Tf * cfg.U
+    audio = torch.rand(B, 1, T - 1, generator=torch.Generator().manual_seed(1)) * 1.6 - 0.8
+    r32, _ = net.forward(aux, audio)
+    r16 = net.forward_bf16(aux, audio)
+    d = (r32 - r16).abs()
+    assert torch.isfinite(r16).all()
+    assert float(d.max()) <= 3e-3 * max(1.0, float(r32.abs().max())), (U, B, Tf, float(d.max()))
+    assert float(d.mean()) <= 3e-4 * max(1.0, float(r32.abs().max()))
