@@ -209,6 +209,109 @@ __global__ __launch_bounds__(64) void step_layer_kernel(const StArgs a, const in
     }
 }
 
+// ---- step_layer for MANY utterances: the wave of a channel pair keeps its 2 K H weights in registers and walks UT utterances
+//      one after the other, the next utterance's activations in flight under the current one's products (two register
+//      sets).  Per-utterance workgroups re-read the weights once per utterance (64 utterances: 954 MB per step through L2);
+//      the 8-utterance tile above holds all eight activation sets at once (192 registers, one wave per SIMD) and lost to
+//      them.  Here a wave needs ~130 registers, the weights cross L2 once per UT utterances, and the sums are the same
+//      lane-by-lane sums as in the kernels above (bit-identical results).  Lane u finishes utterance b0 + u.
+template <int NI, int KIND, int UT>
+__global__ __launch_bounds__(64) void step_layer_seq_kernel(const StArgs a, const int l, const int it) {
+    static_assert(UT <= 64, "one lane finishes one utterance");
+    const SwnGeom& g = a.g;
+    const int lane = threadIdx.x;
+    const int o = blockIdx.x;
+    const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg, KH = K * Hp;
+    const float* P = a.P;
+    const __amdgpu_buffer_rsrc_t rP = st_rsrc(P), rS = st_rsrc(a.state);
+    float4 wz[NI], wc[NI];
+    {
+        const size_t rz = a.y.wd + ((size_t)l * H2 + o) * KH, rc = rz + (size_t)H * KH;
+#pragma unroll
+        for (int pc = 0; pc < NI; ++pc) {
+            const int idx = pc * 256 + lane * 4;
+            wz[pc] = st_ld4(rP, idx < KH ? (unsigned)((rz + idx) * 4) : ST_OOB);
+            wc[pc] = st_ld4(rP, idx < KH ? (unsigned)((rc + idx) * 4) : ST_OOB);
+        }
+    }
+    const int dil = g.dil[l], R = a.ring_len[l];
+    const Iter r = iter_of(a, it);
+    const int b0 = blockIdx.y * UT;
+    const int nb = a.B - b0 < UT ? a.B - b0 : UT;
+    for (int j = 0; j < r.np; ++j) {
+        const int q = r.q0 + j;
+        unsigned xo[NI];                                       // byte offset of this lane's piece inside an utterance's state
+#pragma unroll
+        for (int pc = 0; pc < NI; ++pc) {
+            const int idx = pc * 256 + lane * 4;
+            const int ic = idx < KH ? idx : 0;
+            const int tap = ic / Hp, i = ic - tap * Hp;
+            xo[pc] = idx < KH ? (unsigned)((a.ring_off[l] + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i) * 4) : ST_OOB;
+        }
+        const unsigned ub = (unsigned)a.stride * 4u;           // bytes per utterance
+        float4 xa[NI], xb[NI];
+        auto fetch = [&](float4 (&x)[NI], int u) __attribute__((always_inline)) {
+            const unsigned base = u < nb ? (unsigned)(b0 + u) * ub : ST_OOB;
+#pragma unroll
+            for (int pc = 0; pc < NI; ++pc) x[pc] = st_ld4(rS, base + xo[pc]);      // (an out-of-range base stays out of range)
+        };
+        float myz = 0.f, myc = 0.f;
+        auto dot = [&](const float4 (&x)[NI], int u) __attribute__((always_inline)) {
+            float az = 0.f, ac = 0.f;
+#pragma unroll
+            for (int pc = 0; pc < NI; ++pc) {
+                az = fmaf(wz[pc].x, x[pc].x, az); az = fmaf(wz[pc].y, x[pc].y, az);
+                az = fmaf(wz[pc].z, x[pc].z, az); az = fmaf(wz[pc].w, x[pc].w, az);
+                ac = fmaf(wc[pc].x, x[pc].x, ac); ac = fmaf(wc[pc].y, x[pc].y, ac);
+                ac = fmaf(wc[pc].z, x[pc].z, ac); ac = fmaf(wc[pc].w, x[pc].w, ac);
+            }
+            const float sz = sum64(az), sc = sum64(ac);
+            if (lane == u) { myz = sz; myc = sc; }
+        };
+        fetch(xa, 0);
+        // epilogue operands: issued behind the first activation loads (an exec-masked block that waits for its own loads)
+        float gz = 0.f, gc = 0.f, bdz = 0.f, bdc = 0.f, hp = 0.f;
+        if (lane < nb) {
+            const int b = b0 + lane;
+            const float* st = a.state + (size_t)b * a.stride;
+            gz = P[a.y.bx + (size_t)l * H2 + o]; gc = P[a.y.bx + (size_t)l * H2 + H + o];
+            bdz = P[a.y.bd + (size_t)l * H2 + o]; bdc = P[a.y.bd + (size_t)l * H2 + H + o];
+            hp = st[a.ring_off[l] + (size_t)pmod(q, R) * Hp + o];
+            const float* condb = a.cond + (size_t)b * a.Tf * g.N;
+            for (int s = 0; s < seg; ++s) {
+                int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
+                int f = tt / g.U; const int jj = tt - f * g.U;
+                f = f < a.Tf ? f : a.Tf - 1;
+                const float w = P[a.y.wup + jj];
+                const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
+                gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
+            }
+            if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
+                const int* ihist = reinterpret_cast<const int*>(st + a.o_hist);
+                const int qe = r.gen ? g.rf + r.i : g.rf;
+                const int idx = r.gen ? ihist[q - qe + a.WN - 1] : g.Q / 2;
+                const float* wa = P + a.y.wxa + ((size_t)l * g.Q + idx) * H2;
+                gz += wa[o]; gc += wa[H + o];
+            }
+        }
+#pragma unroll 1
+        for (int u = 0; u < UT; u += 2) {                      // two utterances per trip: static register sets
+            fetch(xb, u + 1);
+            dot(xa, u);
+            fetch(xa, u + 2);
+            dot(xb, u + 1);
+        }
+        if (lane < nb) {
+            float* st = a.state + (size_t)(b0 + lane) * a.stride;
+            const float z = sigm(gz * (myz + bdz));
+            const float c = tanhf(gc * (myc + bdc));
+            const float hn = (1.f - z) * c + z * hp;
+            if (l + 1 < g.L) st[a.ring_off[l + 1] + pmod(q, a.ring_len[l + 1]) * Hp + o] = hn;
+            if (j == r.np - 1) st[a.o_hcat + l * Hp + o] = hn;
+        }
+    }
+}
+
 // ---- rowvec: y[b][row] = act(bias[row] + W[row][:] . x[b][:]), ONE wave per row -------------------------
 template <int BT>
 __global__ __launch_bounds__(64) void rowvec_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
@@ -246,6 +349,57 @@ __global__ __launch_bounds__(64) void rowvec_kernel(const StArgs a, size_t w_off
 #pragma unroll
     for (int u = 0; u < BT; ++u) {
         if (u < nb) { const float sv = sum64(acc[u]); if (lane == u) mine = sv; }
+    }
+    if (lane < nb) {
+        const float v = mine + bias;
+        a.state[(size_t)(b0 + lane) * a.stride + y_off + row] = relu ? fmaxf(v, 0.f) : v;
+    }
+}
+
+// the same for the 1x1 layers: one wave per row, its weights (up to 256 RV inputs: RV float4 per lane) resident, UT utterances
+// one after the other with the next one's inputs in flight
+template <int UT, int RV>
+__global__ __launch_bounds__(64) void rowvec_seq_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
+                                                        int ni, int x_off, int y_off, int relu) {
+    const int lane = threadIdx.x, row = blockIdx.x;
+    const __amdgpu_buffer_rsrc_t rP = st_rsrc(a.P), rS = st_rsrc(a.state);
+    const size_t wr = w_off + (size_t)row * ldw;
+    const float bias = a.P[b_off + row];
+    const int b0 = blockIdx.y * UT;
+    const int nb = a.B - b0 < UT ? a.B - b0 : UT;
+    float4 wv[RV];                                             // host: ni <= 256 RV
+    unsigned xo[RV];
+#pragma unroll
+    for (int pc = 0; pc < RV; ++pc) {
+        const int idx = pc * 256 + lane * 4;
+        wv[pc] = st_ld4(rP, idx < ni ? (unsigned)((wr + idx) * 4) : ST_OOB);
+        xo[pc] = idx < ni ? (unsigned)((x_off + idx) * 4) : ST_OOB;
+    }
+    const unsigned ub = (unsigned)a.stride * 4u;
+    float4 xa[RV], xb[RV];
+    auto fetch = [&](float4 (&x)[RV], int u) __attribute__((always_inline)) {
+        const unsigned base = u < nb ? (unsigned)(b0 + u) * ub : ST_OOB;
+#pragma unroll
+        for (int pc = 0; pc < RV; ++pc) x[pc] = st_ld4(rS, base + xo[pc]);
+    };
+    float mine = 0.f;
+    auto dot = [&](const float4 (&x)[RV], int u) __attribute__((always_inline)) {
+        float acc = 0.f;
+#pragma unroll
+        for (int pc = 0; pc < RV; ++pc) {
+            acc = fmaf(wv[pc].x, x[pc].x, acc); acc = fmaf(wv[pc].y, x[pc].y, acc);
+            acc = fmaf(wv[pc].z, x[pc].z, acc); acc = fmaf(wv[pc].w, x[pc].w, acc);
+        }
+        const float sv = sum64(acc);
+        if (lane == u) mine = sv;
+    };
+    fetch(xa, 0);
+#pragma unroll 1
+    for (int u = 0; u < UT; u += 2) {
+        fetch(xb, u + 1);
+        dot(xa, u);
+        fetch(xa, u + 2);
+        dot(xb, u + 1);
     }
     if (lane < nb) {
         const float v = mine + bias;
@@ -435,9 +589,14 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     // otherwise tiles of 8 utterances share one weight fetch and are processed concurrently
     const bool solo = batch <= 64;
     const unsigned by = solo ? (unsigned)batch : (unsigned)((batch + 7) / 8);
+    // 16 utterances and more: a wave keeps its weight rows and walks SEQ_UT utterances (step_layer_seq / rowvec_seq)
+    constexpr int SEQ_UT = 8;
+    const bool seq = batch >= 16;
+    const unsigned sy = (unsigned)((batch + SEQ_UT - 1) / SEQ_UT);
 #define SWN_LAYER(NI_, KIND_)                                                                                  \
     do {                                                                                                        \
-        if (solo) hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 1>), grid, dim3(64), 0, st, a, l, it);      \
+        if (seq) hipLaunchKernelGGL((step_layer_seq_kernel<NI_, KIND_, SEQ_UT>), dim3(g.H, sy), dim3(64), 0, st, a, l, it); \
+        else if (solo) hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 1>), grid, dim3(64), 0, st, a, l, it);      \
         else hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 8>), grid, dim3(64), 0, st, a, l, it);           \
     } while (0)
     auto layers = [&](int it) {
@@ -456,7 +615,9 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     };
 #undef SWN_LAYER
     auto rowvec = [&](int rows, size_t w_off, int ldw, size_t b_off, int nin, int x_off, int y_off, int relu) {
-        if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
+        if (seq && nin <= 1280) hipLaunchKernelGGL((rowvec_seq_kernel<SEQ_UT, 5>), dim3(rows, sy), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
+        else if (seq && nin <= 2304) hipLaunchKernelGGL((rowvec_seq_kernel<SEQ_UT, 9>), dim3(rows, sy), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
+        else if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
         else hipLaunchKernelGGL(rowvec_kernel<8>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
     };
     const int total = a.n_pro + n_steps;

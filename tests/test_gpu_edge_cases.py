@@ -93,3 +93,39 @@ def test_forward_minimal_length(gpu_ok):
     raw, hs = net.forward(torch.from_numpy(synth_aux(cfg, 2, 1)), torch.zeros(2, 1, cfg.U - cfg.seg), want_hidden=True)
     assert raw.shape == (2, cfg.n_out, cfg.U - 2 * cfg.seg + 1) and torch.isfinite(raw).all()
     assert hs.shape == (2, cfg.L + 1, cfg.H, cfg.U - 2 * cfg.seg + 1)
+
+
+@pytest.mark.parametrize("kind,seg,lpc", [("laplace", 2, 4), ("laplace", 1, 0), ("softmax", 1, 0)])
+def test_stepped_decode_many_utterances_equals_small_batches(gpu_ok, kind, seg, lpc):
+    """from 16 utterances on the stepped decode lets a wave keep its weight rows and walk eight utterances (step_layer_seq /
+    rowvec_seq) instead of re-reading the rows per utterance: same lane-by-lane sums, so a 19-utterance batch (two full
+    groups + a ragged one of three) must equal the same utterances decoded in batches of 10 and 9 bit for bit."""
+    cfg = C.tiny(kind, seg, lpc) if kind == "laplace" else C.tiny("softmax", wav_conv_flag=False)
+    net = _net(cfg)
+    B, Tf = 19, 2
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf))
+    n = Tf * cfg.U // cfg.seg
+    width = cfg.n_quantize if kind == "softmax" else cfg.seg
+    g = torch.Generator().manual_seed(4)
+    noise = (torch.empty(B, n, width).exponential_(1, generator=g) if kind == "softmax"
+             else torch.empty(B, n, width).uniform_(-0.4999, 0.5, generator=g))
+    big, hb = net.decode(aux, n, noise, variant=3, want_heads=True)
+    a, ha = net.decode(aux[:10], n, noise[:10], variant=3, want_heads=True)
+    b, hb2 = net.decode(aux[10:], n, noise[10:], variant=3, want_heads=True)
+    assert torch.equal(big, torch.cat([a, b])) and torch.equal(hb, torch.cat([ha, hb2]))
+    if kind == "laplace":
+        ref, _ = net.decode(aux, n, noise, variant=1)               # the generic persistent kernel
+        assert float((big - ref).abs().max()) <= 1e-5
+
+
+def test_stepped_decode_many_utterances_at_the_run_sh_geometry(gpu_ok):
+    """the same at REF6 (H = 192, K = 7: six float4 pieces per lane and row), 17 utterances, a few generated steps."""
+    cfg = C.ref6_laplace(1, 4)
+    net = _net(cfg)
+    B, n = 17, 24
+    aux = torch.from_numpy(synth_aux(cfg, B, 1))
+    noise = torch.empty(B, n, 1).uniform_(-0.4999, 0.5, generator=torch.Generator().manual_seed(6))
+    big, _ = net.decode(aux, n, noise)                               # auto: stepped, sequential form
+    a, _ = net.decode(aux[:9], n, noise[:9])
+    b, _ = net.decode(aux[9:], n, noise[9:])
+    assert torch.equal(big, torch.cat([a, b]))
