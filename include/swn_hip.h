@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 #define SWN_ABI_VERSION 3   /* 3: `precision` argument instead of a process-wide switch; swn_decode_io.rng_utt_ids_dev;
-                             *    decode variants 4 / 5 retired */
+                             *    decode variants 4 / 5 (cohort, cluster) retired */
 
 /* arithmetic of the training contractions, an argument of every entry point it applies to
  *   FP32: fp32 operands on the matrix cores (v_mfma_f32_16x16x4_f32), bit-compatible with an fmaf chain - the parity
@@ -136,13 +136,10 @@ int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float*
  *   out_dev     laplace: (B, n_steps*seg) fp32 ; softmax: (B, n_steps) int32
  *   heads_dev   optional (B, n_steps, n_out) raw out_2 outputs at each step (may be NULL)
  *   variant     0 = auto, 1 = generic persistent kernel, 2 = register/LDS-resident BL6-class kernel,
- *               3 = stepped multi-launch decode for large geometries (REF6),
- *               4 = cohort decode of large geometries: up to 64 utterances in lock step, lanes = utterances
- *                   (explicit only; auto keeps the stepped decode),
- *               5 = cluster decode of large geometries: ONE persistent launch, the CUs of an XCD carry an utterance
- *                   through every phase and hand the hidden vectors to one another as tagged 8-byte granules
- *                   (6-layer stacks with K = 3 | 7, H <= 256; explicit only).  It needs every workgroup of its grid
- *                   resident at once; if they are not, it gives up within seconds and fills out_dev with NaN / -1   */
+ *               3 = stepped multi-launch decode for large geometries (REF6: what auto picks there)
+ *                   (from 24 utterances on in tiles of 8 channel pairs x 8 utterances that fetch a pair's weight rows once per
+ *                   tile and stage the utterances' activations in LDS).
+ *               Variants 4 and 5 of ABI 2 (cohort / cluster experiments) are retired: SWN_E_BADARG.                       */
 typedef struct swn_decode_io {
     /* sampling noise.  noise_dev != NULL: the host-drawn stream (parity mode; the host draws it with the torch CPU
      * generator in the reference's order): laplace (B, n_steps, seg) uniform(-0.4999, 0.5) draws

@@ -326,27 +326,12 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
                                   int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
                                   void* out, float* heads, void* stream);
 
-// defined in swn_decode_cohort.hip
-extern "C" size_t swn_decode_cohort_state_floats(const swn_net_desc* d, int batch);
-extern "C" int swn_decode_cohort(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
-                                 int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
-                                 void* out, float* heads, void* stream);
-
-// defined in swn_decode_cluster.hip
-extern "C" size_t swn_decode_cluster_state_floats(const swn_net_desc* d, int batch);
-extern "C" int swn_decode_cluster(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
-                                  int n_steps, const SwnNoise* nz, const void* forced, const void* seed, float* state,
-                                  void* out, float* heads, void* stream);
-
 extern "C" size_t swn_decode_state_floats(const swn_net_desc* d, int batch) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1) return 0;
     int off[SWN_MAXL], len[SWN_MAXL];
     size_t a = (size_t)ring_plan(g, off, len) * batch;
-    const size_t b = swn_decode_stepped_state_floats(d, batch), c = swn_decode_cohort_state_floats(d, batch);
-    const size_t e = swn_decode_cluster_state_floats(d, batch);
-    a = a > b ? a : b;
-    a = a > c ? a : c;
-    return a > e ? a : e;                                  // large enough for every kernel variant
+    const size_t b = swn_decode_stepped_state_floats(d, batch);
+    return a > b ? a : b;                                  // large enough for every kernel variant
 }
 
 extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const float* cond, int batch,
@@ -373,10 +358,7 @@ extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const floa
     if (!state) return SWN_E_BADARG;
     // large geometries (REF6: MBs of weights per step) run one launch per phase over many CUs
     const bool big = (size_t)a.g.L * 2 * a.g.H * a.g.K * a.g.Hp >= (size_t)256 * 1024;
-    // variant 4 (cohort: lanes = utterances, weights cross the chip once per step and cohort) is explicit only: it ties
-    // the stepped decode at best (REF6 Laplace B=64: 161 us/step both; softmax 226 vs 268)
-    if (variant == 5) return swn_decode_cluster(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, state, out, heads, stream_);
-    if (variant == 4) return swn_decode_cohort(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, state, out, heads, stream_);
+    if (variant < 0 || variant > 3) return SWN_E_BADARG;   // (4 and 5, the cohort and cluster experiments of ABI 2, are retired)
     if (variant == 3 || (variant == 0 && big)) {
         rc = swn_decode_stepped(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, state, out, heads, stream_);
         if (rc != SWN_E_UNSUPPORTED || variant == 3) return rc;

@@ -60,6 +60,30 @@ __device__ __forceinline__ float sum32(float v) {
     return v;
 }
 
+// 64-lane sums of EIGHT values at once: a butterfly in which a lane keeps half of its values at each of the first three
+// exchanges (xor 32, 16, 8) and sums the survivor over xor 4, 2, 1 - 10 exchanges instead of 8 x 6, and every value goes
+// through exactly the pairings of sum64 in the same order (bit-identical).  Returns utterance (lane >> 3)'s total.
+__device__ __forceinline__ float sum64x8(const float (&v)[8], int lane) {
+    float a4[4], a2[2], a1;
+    const bool h5 = lane & 32, h4 = lane & 16, h3 = lane & 8;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float keep = h5 ? v[k + 4] : v[k], give = h5 ? v[k] : v[k + 4];
+        a4[k] = keep + __shfl_xor(give, 32, 64);
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const float keep = h4 ? a4[k + 2] : a4[k], give = h4 ? a4[k] : a4[k + 2];
+        a2[k] = keep + __shfl_xor(give, 16, 64);
+    }
+    {
+        const float keep = h3 ? a2[1] : a2[0], give = h3 ? a2[0] : a2[1];
+        a1 = keep + __shfl_xor(give, 8, 64);
+    }
+    a1 += __shfl_xor(a1, 4, 64); a1 += __shfl_xor(a1, 2, 64); a1 += __shfl_xor(a1, 1, 64);
+    return a1;
+}
+
 // iteration `it` of the per-utterance counter: it < n_pro is a prologue position, else generation step
 struct Iter { bool gen; int i, np, q0; };
 __device__ __forceinline__ Iter iter_of(const StArgs& a, int it) {
@@ -209,70 +233,63 @@ __global__ __launch_bounds__(64) void step_layer_kernel(const StArgs a, const in
     }
 }
 
-// ---- step_layer for MANY utterances: the wave of a channel pair keeps its 2 K H weights in registers and walks UT utterances
-//      one after the other, the next utterance's activations in flight under the current one's products (two register
-//      sets).  Per-utterance workgroups re-read the weights once per utterance (64 utterances: 954 MB per step through L2);
-//      the 8-utterance tile above holds all eight activation sets at once (192 registers, one wave per SIMD) and lost to
-//      them.  Here a wave needs ~130 registers, the weights cross L2 once per UT utterances, and the sums are the same
-//      lane-by-lane sums as in the kernels above (bit-identical results).  Lane u finishes utterance b0 + u.
-template <int NI, int KIND, int UT>
-__global__ __launch_bounds__(64) void step_layer_seq_kernel(const StArgs a, const int l, const int it) {
-    static_assert(UT <= 64, "one lane finishes one utterance");
+// ---- step_layer for MANY utterances: a 512-thread workgroup = 8 channel pairs x 8 utterances.  Per-utterance workgroups
+//      re-read a pair's weight rows once per utterance and every pair's wave re-reads the utterance's K H activations:
+//      98 MB through L2 per layer launch at 64 utterances, 9.5 us - the launch is bound by that traffic, not by latency.
+//      Here wave w keeps the 2 K H weights of pair 8 bx + w in registers (fetched once per 8 utterances), wave u stages the
+//      activations of utterance 8 by + u in LDS (fetched once per 8 pairs: 25 MB per launch), and after ONE barrier every
+//      wave forms its pair's two sums for the eight utterances out of LDS - the same lane-by-lane sums as the kernels above
+//      (bit-identical results).  Lane 8 u of a wave finishes utterance u.
+constexpr int ST_TU = 8;                                       // utterances (= waves) of a tile
+template <int NI, int KIND>
+__global__ __launch_bounds__(64 * ST_TU) void step_layer_tile_kernel(const StArgs a, const int l, const int it) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [ST_TU][NI * 256]
     const SwnGeom& g = a.g;
-    const int lane = threadIdx.x;
-    const int o = blockIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int o = blockIdx.x * ST_TU + w;
     const int H = g.H, Hp = g.Hp, K = g.K, H2 = 2 * g.H, seg = g.seg, KH = K * Hp;
+    const bool live = o < H;
     const float* P = a.P;
     const __amdgpu_buffer_rsrc_t rP = st_rsrc(P), rS = st_rsrc(a.state);
     float4 wz[NI], wc[NI];
     {
-        const size_t rz = a.y.wd + ((size_t)l * H2 + o) * KH, rc = rz + (size_t)H * KH;
+        const size_t rz = a.y.wd + ((size_t)l * H2 + (live ? o : 0)) * KH, rc = rz + (size_t)H * KH;
 #pragma unroll
         for (int pc = 0; pc < NI; ++pc) {
             const int idx = pc * 256 + lane * 4;
-            wz[pc] = st_ld4(rP, idx < KH ? (unsigned)((rz + idx) * 4) : ST_OOB);
-            wc[pc] = st_ld4(rP, idx < KH ? (unsigned)((rc + idx) * 4) : ST_OOB);
+            const bool ok = live && idx < KH;
+            wz[pc] = st_ld4(rP, ok ? (unsigned)((rz + idx) * 4) : ST_OOB);
+            wc[pc] = st_ld4(rP, ok ? (unsigned)((rc + idx) * 4) : ST_OOB);
         }
     }
     const int dil = g.dil[l], R = a.ring_len[l];
     const Iter r = iter_of(a, it);
-    const int b0 = blockIdx.y * UT;
-    const int nb = a.B - b0 < UT ? a.B - b0 : UT;
+    const int b0 = blockIdx.y * ST_TU;
+    const int nb = a.B - b0 < ST_TU ? a.B - b0 : ST_TU;
     for (int j = 0; j < r.np; ++j) {
         const int q = r.q0 + j;
-        unsigned xo[NI];                                       // byte offset of this lane's piece inside an utterance's state
-#pragma unroll
-        for (int pc = 0; pc < NI; ++pc) {
-            const int idx = pc * 256 + lane * 4;
-            const int ic = idx < KH ? idx : 0;
-            const int tap = ic / Hp, i = ic - tap * Hp;
-            xo[pc] = idx < KH ? (unsigned)((a.ring_off[l] + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i) * 4) : ST_OOB;
-        }
-        const unsigned ub = (unsigned)a.stride * 4u;           // bytes per utterance
-        float4 xa[NI], xb[NI];
-        auto fetch = [&](float4 (&x)[NI], int u) __attribute__((always_inline)) {
-            const unsigned base = u < nb ? (unsigned)(b0 + u) * ub : ST_OOB;
-#pragma unroll
-            for (int pc = 0; pc < NI; ++pc) x[pc] = st_ld4(rS, base + xo[pc]);      // (an out-of-range base stays out of range)
-        };
-        float myz = 0.f, myc = 0.f;
-        auto dot = [&](const float4 (&x)[NI], int u) __attribute__((always_inline)) {
-            float az = 0.f, ac = 0.f;
+        // wave w stages utterance b0 + w
+        {
+            float4 xv[NI];
 #pragma unroll
             for (int pc = 0; pc < NI; ++pc) {
-                az = fmaf(wz[pc].x, x[pc].x, az); az = fmaf(wz[pc].y, x[pc].y, az);
-                az = fmaf(wz[pc].z, x[pc].z, az); az = fmaf(wz[pc].w, x[pc].w, az);
-                ac = fmaf(wc[pc].x, x[pc].x, ac); ac = fmaf(wc[pc].y, x[pc].y, ac);
-                ac = fmaf(wc[pc].z, x[pc].z, ac); ac = fmaf(wc[pc].w, x[pc].w, ac);
+                const int idx = pc * 256 + lane * 4;
+                const int ic = idx < KH ? idx : 0;
+                const int tap = ic / Hp, i = ic - tap * Hp;
+                const size_t xo = a.ring_off[l] + (size_t)pmod(q - (K - 1 - tap) * dil, R) * Hp + i;
+                xv[pc] = st_ld4(rS, (idx < KH && w < nb) ? (unsigned)(((size_t)(b0 + w) * a.stride + xo) * 4) : ST_OOB);
             }
-            const float sz = sum64(az), sc = sum64(ac);
-            if (lane == u) { myz = sz; myc = sc; }
-        };
-        fetch(xa, 0);
-        // epilogue operands: issued behind the first activation loads (an exec-masked block that waits for its own loads)
+            if (j > 0) __syncthreads();                        // the previous position's sums are done with the buffer
+#pragma unroll
+            for (int pc = 0; pc < NI; ++pc) *reinterpret_cast<float4*>(xs + (w * NI + pc) * 256 + lane * 4) = xv[pc];
+        }
+        // epilogue operands: issued behind the activation loads (an exec-masked block that waits for its own loads)
         float gz = 0.f, gc = 0.f, bdz = 0.f, bdc = 0.f, hp = 0.f;
-        if (lane < nb) {
-            const int b = b0 + lane;
+        const int ut = lane >> 3;                              // the utterance this lane's octet ends up with (sum64x8)
+        const bool fin = (lane & 7) == 0 && ut < nb && live;
+        if (fin) {
+            const int b = b0 + ut;
             const float* st = a.state + (size_t)b * a.stride;
             gz = P[a.y.bx + (size_t)l * H2 + o]; gc = P[a.y.bx + (size_t)l * H2 + H + o];
             bdz = P[a.y.bd + (size_t)l * H2 + o]; bdc = P[a.y.bd + (size_t)l * H2 + H + o];
@@ -282,9 +299,9 @@ __global__ __launch_bounds__(64) void step_layer_seq_kernel(const StArgs a, cons
                 int tt = q + s - g.rf; tt = tt < 0 ? 0 : tt;
                 int f = tt / g.U; const int jj = tt - f * g.U;
                 f = f < a.Tf ? f : a.Tf - 1;
-                const float w = P[a.y.wup + jj];
+                const float wv = P[a.y.wup + jj];
                 const float* cr = condb + (size_t)f * g.N + (size_t)(l * seg + s) * H2;
-                gz = fmaf(w, cr[o], gz); gc = fmaf(w, cr[H + o], gc);
+                gz = fmaf(wv, cr[o], gz); gc = fmaf(wv, cr[H + o], gc);
             }
             if (KIND == SWN_KIND_SOFTMAX && g.audio_in) {
                 const int* ihist = reinterpret_cast<const int*>(st + a.o_hist);
@@ -294,15 +311,24 @@ __global__ __launch_bounds__(64) void step_layer_seq_kernel(const StArgs a, cons
                 gz += wa[o]; gc += wa[H + o];
             }
         }
-#pragma unroll 1
-        for (int u = 0; u < UT; u += 2) {                      // two utterances per trip: static register sets
-            fetch(xb, u + 1);
-            dot(xa, u);
-            fetch(xa, u + 2);
-            dot(xb, u + 1);
+        __syncthreads();
+        float azv[ST_TU], acv[ST_TU];
+#pragma unroll
+        for (int u = 0; u < ST_TU; ++u) {
+            float az = 0.f, ac = 0.f;
+#pragma unroll
+            for (int pc = 0; pc < NI; ++pc) {
+                const float4 x = *reinterpret_cast<const float4*>(xs + (u * NI + pc) * 256 + lane * 4);
+                az = fmaf(wz[pc].x, x.x, az); az = fmaf(wz[pc].y, x.y, az);
+                az = fmaf(wz[pc].z, x.z, az); az = fmaf(wz[pc].w, x.w, az);
+                ac = fmaf(wc[pc].x, x.x, ac); ac = fmaf(wc[pc].y, x.y, ac);
+                ac = fmaf(wc[pc].z, x.z, ac); ac = fmaf(wc[pc].w, x.w, ac);
+            }
+            azv[u] = az; acv[u] = ac;
         }
-        if (lane < nb) {
-            float* st = a.state + (size_t)(b0 + lane) * a.stride;
+        const float myz = sum64x8(azv, lane), myc = sum64x8(acv, lane);
+        if (fin) {
+            float* st = a.state + (size_t)(b0 + ut) * a.stride;
             const float z = sigm(gz * (myz + bdz));
             const float c = tanhf(gc * (myc + bdc));
             const float hn = (1.f - z) * c + z * hp;
@@ -356,54 +382,51 @@ __global__ __launch_bounds__(64) void rowvec_kernel(const StArgs a, size_t w_off
     }
 }
 
-// the same for the 1x1 layers: one wave per row, its weights (up to 256 RV inputs: RV float4 per lane) resident, UT utterances
-// one after the other with the next one's inputs in flight
-template <int UT, int RV>
-__global__ __launch_bounds__(64) void rowvec_seq_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
-                                                        int ni, int x_off, int y_off, int relu) {
-    const int lane = threadIdx.x, row = blockIdx.x;
+// the same for the 1x1 layers: 8 rows x 8 utterances per workgroup, the utterances' input vectors staged in LDS
+template <int RV>                                              // host: ni <= 256 RV
+__global__ __launch_bounds__(64 * ST_TU) void rowvec_tile_kernel(const StArgs a, size_t w_off, int ldw, size_t b_off, int rows,
+                                                                 int ni, int x_off, int y_off, int relu) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [ST_TU][RV * 256]
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int row = blockIdx.x * ST_TU + w;
+    const bool live = row < rows;
     const __amdgpu_buffer_rsrc_t rP = st_rsrc(a.P), rS = st_rsrc(a.state);
-    const size_t wr = w_off + (size_t)row * ldw;
-    const float bias = a.P[b_off + row];
-    const int b0 = blockIdx.y * UT;
-    const int nb = a.B - b0 < UT ? a.B - b0 : UT;
-    float4 wv[RV];                                             // host: ni <= 256 RV
-    unsigned xo[RV];
+    const size_t wr = w_off + (size_t)(live ? row : 0) * ldw;
+    const float bias = live ? a.P[b_off + row] : 0.f;
+    const int b0 = blockIdx.y * ST_TU;
+    const int nb = a.B - b0 < ST_TU ? a.B - b0 : ST_TU;
+    float4 wv[RV];
+    {
+        float4 xv[RV];
 #pragma unroll
-    for (int pc = 0; pc < RV; ++pc) {
-        const int idx = pc * 256 + lane * 4;
-        wv[pc] = st_ld4(rP, idx < ni ? (unsigned)((wr + idx) * 4) : ST_OOB);
-        xo[pc] = idx < ni ? (unsigned)((x_off + idx) * 4) : ST_OOB;
+        for (int pc = 0; pc < RV; ++pc) {
+            const int idx = pc * 256 + lane * 4;
+            const bool ok = idx < ni;
+            wv[pc] = st_ld4(rP, (ok && live) ? (unsigned)((wr + idx) * 4) : ST_OOB);
+            xv[pc] = st_ld4(rS, (ok && w < nb) ? (unsigned)(((size_t)(b0 + w) * a.stride + x_off + idx) * 4) : ST_OOB);
+        }
+#pragma unroll
+        for (int pc = 0; pc < RV; ++pc) *reinterpret_cast<float4*>(xs + (w * RV + pc) * 256 + lane * 4) = xv[pc];
     }
-    const unsigned ub = (unsigned)a.stride * 4u;
-    float4 xa[RV], xb[RV];
-    auto fetch = [&](float4 (&x)[RV], int u) __attribute__((always_inline)) {
-        const unsigned base = u < nb ? (unsigned)(b0 + u) * ub : ST_OOB;
+    __syncthreads();
+    float accv[ST_TU];
 #pragma unroll
-        for (int pc = 0; pc < RV; ++pc) x[pc] = st_ld4(rS, base + xo[pc]);
-    };
-    float mine = 0.f;
-    auto dot = [&](const float4 (&x)[RV], int u) __attribute__((always_inline)) {
+    for (int u = 0; u < ST_TU; ++u) {
         float acc = 0.f;
 #pragma unroll
         for (int pc = 0; pc < RV; ++pc) {
-            acc = fmaf(wv[pc].x, x[pc].x, acc); acc = fmaf(wv[pc].y, x[pc].y, acc);
-            acc = fmaf(wv[pc].z, x[pc].z, acc); acc = fmaf(wv[pc].w, x[pc].w, acc);
+            const float4 x = *reinterpret_cast<const float4*>(xs + (u * RV + pc) * 256 + lane * 4);
+            acc = fmaf(wv[pc].x, x.x, acc); acc = fmaf(wv[pc].y, x.y, acc);
+            acc = fmaf(wv[pc].z, x.z, acc); acc = fmaf(wv[pc].w, x.w, acc);
         }
-        const float sv = sum64(acc);
-        if (lane == u) mine = sv;
-    };
-    fetch(xa, 0);
-#pragma unroll 1
-    for (int u = 0; u < UT; u += 2) {
-        fetch(xb, u + 1);
-        dot(xa, u);
-        fetch(xa, u + 2);
-        dot(xb, u + 1);
+        accv[u] = acc;
     }
-    if (lane < nb) {
+    const float mine = sum64x8(accv, lane);
+    const int ut = lane >> 3;
+    if ((lane & 7) == 0 && ut < nb && live) {
         const float v = mine + bias;
-        a.state[(size_t)(b0 + lane) * a.stride + y_off + row] = relu ? fmaxf(v, 0.f) : v;
+        a.state[(size_t)(b0 + ut) * a.stride + y_off + row] = relu ? fmaxf(v, 0.f) : v;
     }
 }
 
@@ -589,13 +612,24 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     // otherwise tiles of 8 utterances share one weight fetch and are processed concurrently
     const bool solo = batch <= 64;
     const unsigned by = solo ? (unsigned)batch : (unsigned)((batch + 7) / 8);
-    // 16 utterances and more: a wave keeps its weight rows and walks SEQ_UT utterances (step_layer_seq / rowvec_seq)
-    constexpr int SEQ_UT = 8;
-    const bool seq = batch >= 16;
-    const unsigned sy = (unsigned)((batch + SEQ_UT - 1) / SEQ_UT);
+    // many utterances: tiles of 8 channel pairs (rows) x 8 utterances (step_layer_tile / rowvec_tile)
+    const bool seq = batch >= 24;                              // measured crossover at REF6: 16 utterances 47 (solo) / 53 us per step, 24: 59 / 56
+    const unsigned sy = (unsigned)((batch + ST_TU - 1) / ST_TU);
+    if (seq) {
+        static bool attr_set = false;                          // dynamic LDS above 64 KB (NI = 8: 64 KB, RV = 9: 72 KB)
+        if (!attr_set) {
+            const int big = 72 * 1024;
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(step_layer_tile_kernel<8, SWN_KIND_LAPLACE>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(step_layer_tile_kernel<8, SWN_KIND_SOFTMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(rowvec_tile_kernel<9>), hipFuncAttributeMaxDynamicSharedMemorySize, big) != hipSuccess)
+                return SWN_E_LAUNCH;
+            attr_set = true;
+        }
+    }
 #define SWN_LAYER(NI_, KIND_)                                                                                  \
     do {                                                                                                        \
-        if (seq) hipLaunchKernelGGL((step_layer_seq_kernel<NI_, KIND_, SEQ_UT>), dim3(g.H, sy), dim3(64), 0, st, a, l, it); \
+        if (seq) hipLaunchKernelGGL((step_layer_tile_kernel<NI_, KIND_>), dim3((g.H + ST_TU - 1) / ST_TU, sy), dim3(64 * ST_TU), \
+                                    (size_t)ST_TU * NI_ * 256 * sizeof(float), st, a, l, it);                  \
         else if (solo) hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 1>), grid, dim3(64), 0, st, a, l, it);      \
         else hipLaunchKernelGGL((step_layer_kernel<NI_, KIND_, 8>), grid, dim3(64), 0, st, a, l, it);           \
     } while (0)
@@ -615,8 +649,8 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
     };
 #undef SWN_LAYER
     auto rowvec = [&](int rows, size_t w_off, int ldw, size_t b_off, int nin, int x_off, int y_off, int relu) {
-        if (seq && nin <= 1280) hipLaunchKernelGGL((rowvec_seq_kernel<SEQ_UT, 5>), dim3(rows, sy), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
-        else if (seq && nin <= 2304) hipLaunchKernelGGL((rowvec_seq_kernel<SEQ_UT, 9>), dim3(rows, sy), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
+        if (seq && nin <= 1280) hipLaunchKernelGGL(rowvec_tile_kernel<5>, dim3((rows + ST_TU - 1) / ST_TU, sy), dim3(64 * ST_TU), (size_t)ST_TU * 5 * 1024, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
+        else if (seq && nin <= 2304) hipLaunchKernelGGL(rowvec_tile_kernel<9>, dim3((rows + ST_TU - 1) / ST_TU, sy), dim3(64 * ST_TU), (size_t)ST_TU * 9 * 1024, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
         else if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
         else hipLaunchKernelGGL(rowvec_kernel<8>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
     };

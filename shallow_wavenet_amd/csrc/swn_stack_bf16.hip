@@ -1041,8 +1041,11 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;      // persistent: one workgroup (4 waves x 512 VGPRs) per CU
     const int nch = (g.U + 15) / 16;
 #if !defined(SWN_OLD_UNITS)           // diagnostic builds only: the per-layer launches for A/B timing
-    if (g.seg == 1 && g.U >= 33 && nch <= 7 && g.L == FZ_NL) {
-        // all six gated layers in one launch (bf16_stack_fused_kernel): one workgroup per CU walks a contiguous range of frames
+    // all six gated layers in one launch (bf16_stack_fused_kernel): one workgroup per CU walks a contiguous range of frames.
+    // Up to ~12 frames per workgroup (cfg4's own 8 x 150: 4.7) it beats six per-layer launches (4 x 150: 0.091 / 0.104 ms,
+    // 8 x 150: 0.122 / 0.141, 16 x 150: 0.198 / 0.221); from 32 x 150 on the two tie (0.369 / 0.363, 64 x 150: 0.713 / 0.707) and
+    // the per-layer kernels, which need no halo, keep the large sizes
+    if (g.seg == 1 && g.U >= 33 && nch <= 7 && g.L == FZ_NL && batch * ((int)((Tp - 1 + a.coff) / g.U) + 1) <= 3072) {
         const int Fu = (int)((Tp - 1 + a.coff) / g.U) + 1;           // frames per utterance
         const int n_fr = batch * Fu;
         const int ug = n_fr < 256 ? n_fr : 256;

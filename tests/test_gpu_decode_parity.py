@@ -31,11 +31,8 @@ def _net(cfg, d):
 
 
 def _variants(cfg):
-    """1 generic persistent, 3 stepped multi-launch, 4 cohort (lanes = utterances), 5 cluster (one persistent launch,
-    the CUs of an XCD hand the hidden vectors to one another; 6-layer stacks with K = 3 | 7), 0 auto (BL6 fast kernel /
-    stepped for REF6)"""
-    cluster = cfg.L == 6 and cfg.K in (3, 7) and not cfg.audio_in_flag
-    return [1, 3, 4] + ([5] if cluster else []) + [0]
+    """1 generic persistent, 3 stepped multi-launch, 0 auto (BL6 fast kernel / stepped for REF6)"""
+    return [1, 3, 0]
 
 
 @pytest.mark.parametrize("name", LAP)

@@ -97,12 +97,14 @@ def test_forward_minimal_length(gpu_ok):
 
 @pytest.mark.parametrize("kind,seg,lpc", [("laplace", 2, 4), ("laplace", 1, 0), ("softmax", 1, 0)])
 def test_stepped_decode_many_utterances_equals_small_batches(gpu_ok, kind, seg, lpc):
-    """from 16 utterances on the stepped decode lets a wave keep its weight rows and walk eight utterances (step_layer_seq /
-    rowvec_seq) instead of re-reading the rows per utterance: same lane-by-lane sums, so a 19-utterance batch (two full
-    groups + a ragged one of three) must equal the same utterances decoded in batches of 10 and 9 bit for bit."""
+    """from 24 utterances on the stepped decode works in tiles of 8 channel pairs x 8 utterances (step_layer_tile /
+    rowvec_tile: a pair's weight rows fetched once per tile, the utterances' activations staged in LDS, the eight 64-lane
+    sums formed by one butterfly) instead of one workgroup per pair and utterance: the same lane-by-lane sums in the same
+    order, so a 27-utterance batch (three full tiles + a ragged one of three) must equal the same utterances decoded in
+    batches of 14 and 13 bit for bit."""
     cfg = C.tiny(kind, seg, lpc) if kind == "laplace" else C.tiny("softmax", wav_conv_flag=False)
     net = _net(cfg)
-    B, Tf = 19, 2
+    B, Tf = 27, 2
     aux = torch.from_numpy(synth_aux(cfg, B, Tf))
     n = Tf * cfg.U // cfg.seg
     width = cfg.n_quantize if kind == "softmax" else cfg.seg
@@ -110,8 +112,8 @@ def test_stepped_decode_many_utterances_equals_small_batches(gpu_ok, kind, seg, 
     noise = (torch.empty(B, n, width).exponential_(1, generator=g) if kind == "softmax"
              else torch.empty(B, n, width).uniform_(-0.4999, 0.5, generator=g))
     big, hb = net.decode(aux, n, noise, variant=3, want_heads=True)
-    a, ha = net.decode(aux[:10], n, noise[:10], variant=3, want_heads=True)
-    b, hb2 = net.decode(aux[10:], n, noise[10:], variant=3, want_heads=True)
+    a, ha = net.decode(aux[:14], n, noise[:14], variant=3, want_heads=True)
+    b, hb2 = net.decode(aux[14:], n, noise[14:], variant=3, want_heads=True)
     assert torch.equal(big, torch.cat([a, b])) and torch.equal(hb, torch.cat([ha, hb2]))
     if kind == "laplace":
         ref, _ = net.decode(aux, n, noise, variant=1)               # the generic persistent kernel
@@ -119,13 +121,13 @@ def test_stepped_decode_many_utterances_equals_small_batches(gpu_ok, kind, seg, 
 
 
 def test_stepped_decode_many_utterances_at_the_run_sh_geometry(gpu_ok):
-    """the same at REF6 (H = 192, K = 7: six float4 pieces per lane and row), 17 utterances, a few generated steps."""
+    """the same at REF6 (H = 192, K = 7: six float4 pieces per lane and row), 25 utterances, a few generated steps."""
     cfg = C.ref6_laplace(1, 4)
     net = _net(cfg)
-    B, n = 17, 24
+    B, n = 25, 24
     aux = torch.from_numpy(synth_aux(cfg, B, 1))
     noise = torch.empty(B, n, 1).uniform_(-0.4999, 0.5, generator=torch.Generator().manual_seed(6))
-    big, _ = net.decode(aux, n, noise)                               # auto: stepped, sequential form
-    a, _ = net.decode(aux[:9], n, noise[:9])
-    b, _ = net.decode(aux[9:], n, noise[9:])
+    big, _ = net.decode(aux, n, noise)                               # auto: stepped decode, tiles
+    a, _ = net.decode(aux[:13], n, noise[:13])
+    b, _ = net.decode(aux[13:], n, noise[13:])
     assert torch.equal(big, torch.cat([a, b]))
