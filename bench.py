@@ -519,9 +519,11 @@ def main():
     rank, world, local = D.init_from_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
-    dev = torch.device("cuda", local)
+    n_dev = torch.cuda.device_count()
+    shared = world > n_dev                                       # rehearsal on a box with fewer GPUs than ranks: the ranks share
+    dev = torch.device("cuda", local % n_dev)                    # the cards (dist.py then talks gloo, not RCCL)
     torch.cuda.set_device(dev)
-    ranks_seen = int(round(D.sum_over_ranks(1.0, dev)))          # what RCCL actually connected
+    ranks_seen = int(round(D.sum_over_ranks(1.0, dev)))          # what the process group actually connected
     if ranks_seen != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the all-reduce saw {ranks_seen} rank(s)")
 
@@ -587,6 +589,8 @@ def main():
                      "note": "latency-bound sequential chain; working set on-chip"},
         "legs_doc": "profiles/LEGS.md (units, kernels, pricing per leg; frac_design = priced on the design's own stream bytes)",
     }
+    if shared:
+        line["rehearsal"] = f"{world} ranks share {n_dev} GPU(s) over gloo: the N > 1 code path, not a scaling measurement"
     detail = {}
     # cfg5 (64 utterances per rank) on every rank at every N: the scaling curve's second line
     try:

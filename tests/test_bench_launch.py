@@ -50,3 +50,23 @@ def test_single_rank_needs_no_launcher():
     r = _run(["--gpus", "1", "--plan-only"])
     assert r.returncode == 0, r.stderr[-2000:]
     assert _line(r.stdout)["n_gpus"] == 1
+
+
+import pytest
+
+
+@pytest.mark.gpu
+def test_two_rank_bench_rehearsal_on_one_gpu():
+    """the whole N > 1 path of bench.py as the plain command runs it - self-launch, torchrun environment, packed-weight
+    broadcast, per-rank decode, cfg5 leg on every rank, barrier + max over ranks, ONE line from rank 0 - with two ranks sharing
+    the box's GPU (gloo instead of RCCL: the line says so; it is not a scaling measurement)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs a HIP device")
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "1", "--frames", "20", "--no-cpu-baseline"], timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == 2 and line["scaling"] == "weak"
+    assert line["value"] > 0 and "cfg5" in line["legs"] and line["legs"]["cfg5"]["value"] > 0
+    if torch.cuda.device_count() < 2:
+        assert "rehearsal" in line
