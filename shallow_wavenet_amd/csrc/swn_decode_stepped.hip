@@ -551,6 +551,127 @@ __global__ __launch_bounds__(256) void step_tail_kernel(const StArgs a, const in
     if (i + 1 < a.n_steps) input_layer<KIND>(a, st, it + 1, tid, 256, lwin);
 }
 
+// ---- step_tail of the Laplace nets with every global operand requested up front.  The kernel above pays its dependent
+//      round trips one after the other (out_2 operands, the out_2 bias, the LP window, the noise draw, the window shift, the
+//      input layer's taps: 7.4-8.1 us per launch, the longest of the chain); nothing of that depends on out_2 except the
+//      arithmetic, so here the sample window, the step's noise draws, the out_2 bias and the K + 1 parameter rows of the
+//      next input layer are all in flight with the out_2 operands, and what follows the first barrier works on LDS and
+//      registers.  Same formulas in the same order as step_tail_kernel<LAPLACE> + input_layer (bit-identical results).
+template <int MAXE>      // elements (channel, position) of the next input layer per thread: ceil(H * seg / 256) <= MAXE
+__global__ __launch_bounds__(256) void step_tail_laplace_kernel(const StArgs a, const int it) {
+    __shared__ float o2v[64];                  // NO <= 48
+    __shared__ float lwin[32];                 // the updated sample window, for the fused next input layer
+    __shared__ float lold[32];                 // the window as the step found it
+    __shared__ float lnz[16];                  // the step's noise draws
+    const SwnGeom& g = a.g;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 31, grp = tid >> 5;
+    float* st = a.state + (size_t)b * a.stride;
+    const int i = it - a.n_pro, seg = g.seg, WN = a.WN, H = g.H, K = g.K;
+    const float* P = a.P;
+    float* shist = st + a.o_hist;
+    // ---- requests: out_2 rows and bias, window, noise, input-layer parameters
+    const __amdgpu_buffer_rsrc_t rP = st_rsrc(P), rS = st_rsrc(a.state);
+    const size_t xb = (size_t)b * a.stride + a.o_o1;
+    const int nin = g.O1p;                     // <= 512 (host)
+    float4 wv[4], wv2[4], xv[4];
+    const bool rok = grp < g.NO, rok2 = grp + 8 < g.NO;          // NO <= 16 (host): rows grp and grp + 8 of the 32-lane group
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int idx = u * 128 + lane * 4;
+        wv[u] = st_ld4(rP, (rok && idx < nin) ? (unsigned)((a.y.w2 + (size_t)grp * g.O1p + idx) * 4) : ST_OOB);
+        wv2[u] = st_ld4(rP, (rok2 && idx < nin) ? (unsigned)((a.y.w2 + (size_t)(grp + 8) * g.O1p + idx) * 4) : ST_OOB);
+        xv[u] = st_ld4(rS, (rok && idx < nin) ? (unsigned)((xb + idx) * 4) : ST_OOB);
+    }
+    const float b2v = st_ld1(rP, (rok && lane == 0) ? (unsigned)((a.y.b2 + grp) * 4) : ST_OOB);
+    const float b2v2 = st_ld1(rP, (rok2 && lane == 0) ? (unsigned)((a.y.b2 + grp + 8) * 4) : ST_OOB);
+    const float hv = st_ld1(rS, tid < WN ? (unsigned)((((size_t)b * a.stride) + a.o_hist + tid) * 4) : ST_OOB);
+    float ev = 0.f;
+    if (tid >= 64 && tid < 64 + seg) ev = swn_noise_laplace(a.nz, b, i, tid - 64, a.n_steps, seg);
+    // next input layer (iteration it + 1, a generation step): element e = tid + 256 m -> position j = e / H, channel o
+    const bool more = i + 1 < a.n_steps;
+    float pcb[MAXE], pcv[MAXE][8], pcc[MAXE][8];
+#pragma unroll
+    for (int m = 0; m < MAXE; ++m) {
+        const int e = tid + 256 * m;
+        const bool ok = more && e < H * seg;
+        const int o = ok ? e % H : 0;
+        pcb[m] = st_ld1(rP, ok ? (unsigned)((a.y.cb + o) * 4) : ST_OOB);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            pcv[m][k] = st_ld1(rP, (ok && k < K) ? (unsigned)((a.y.cv + (size_t)k * H + o) * 4) : ST_OOB);
+            pcc[m][k] = st_ld1(rP, (ok && k < K) ? (unsigned)((a.y.cc + (size_t)k * H + o) * 4) : ST_OOB);
+        }
+    }
+    // ---- out_2 (NO <= 16 rows, O1p <= 512 inputs: one pass over the inputs per row)
+    {
+        float acc = 0.f, acc2 = 0.f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc = fmaf(wv[u].x, xv[u].x, acc); acc = fmaf(wv[u].y, xv[u].y, acc);
+            acc = fmaf(wv[u].z, xv[u].z, acc); acc = fmaf(wv[u].w, xv[u].w, acc);
+            acc2 = fmaf(wv2[u].x, xv[u].x, acc2); acc2 = fmaf(wv2[u].y, xv[u].y, acc2);
+            acc2 = fmaf(wv2[u].z, xv[u].z, acc2); acc2 = fmaf(wv2[u].w, xv[u].w, acc2);
+        }
+        acc = sum32(acc); acc2 = sum32(acc2);
+        if (lane == 0 && rok) o2v[grp] = acc + b2v;
+        if (lane == 0 && rok2) o2v[grp + 8] = acc2 + b2v2;
+    }
+    if (tid < WN) lold[tid] = hv;
+    if (tid >= 64 && tid < 64 + seg) lnz[tid - 64] = ev;
+    __syncthreads();
+    if (a.heads) for (int e = tid; e < g.NO; e += 256) a.heads[((size_t)b * a.n_steps + i) * g.NO + e] = o2v[e];
+    if (tid == 0) {
+#pragma clang fp contract(off)
+        // Laplace head, cswnv_shift1.py:368-391
+        const float* forced = reinterpret_cast<const float*>(a.forced);
+        float* outp = reinterpret_cast<float*>(a.out) + (size_t)b * a.n_steps * seg + (size_t)i * seg;
+        float lp[16], fed[16];
+        const int lpc = g.lpc;
+        for (int k = 0; k < lpc; ++k) lp[k] = lold[WN - lpc + k];
+        for (int j = 0; j < seg; ++j) {
+            const float mu = o2v[j], yv = o2v[seg + j];
+            const float bsc = expf(fminf(yv, 0.f) - log1pf(expf(-fabsf(yv))));
+            float lpv = 0.f;
+            for (int k = 0; k < lpc; ++k) lpv += o2v[2 * seg + lpc - 1 - k] * lp[k];
+            const float e = lnz[j];
+            const float sg = (e > 0.f) ? 1.f : ((e < 0.f) ? -1.f : 0.f);
+            const float t = (bsc * sg) * log1pf(-2.f * fabsf(e));
+            float sv = (lpc > 0) ? (lpv + mu) - t : mu - t;
+            sv = fminf(fmaxf(sv, -1.f), 1.f);
+            outp[j] = sv;
+            const float fd = forced ? forced[(size_t)b * a.n_steps * seg + (size_t)i * seg + j] : sv;
+            fed[j] = fd;
+            for (int k = 0; k + 1 < lpc; ++k) lp[k] = lp[k + 1];
+            if (lpc > 0) lp[lpc - 1] = fd;
+        }
+        for (int k = 0; k + seg < WN; ++k) { const float v = lold[k + seg]; shist[k] = v; lwin[k] = v; }
+        for (int j = 0; j < seg; ++j) { shist[WN - seg + j] = fed[j]; lwin[WN - seg + j] = fed[j]; }
+    }
+    __syncthreads();
+    if (!more) return;
+    // ---- input layer of iteration it + 1 out of the prefetched rows (input_layer<LAPLACE>, generation form)
+    const int i1 = i + 1;
+    const int q0 = g.rf + 1 - seg + i1 * seg, qe = g.rf + i1 * seg;
+#pragma unroll
+    for (int m = 0; m < MAXE; ++m) {
+        const int e = tid + 256 * m;
+        if (e < H * seg) {
+            const int j = e / H, o = e - j * H, q = q0 + j;
+            float acc = pcb[m];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                if (k < K) {
+                    const int rr = q - (K - 1 - k);
+                    int wi = rr - qe + WN - 1; wi = wi < 0 ? 0 : (wi >= WN ? WN - 1 : wi);
+                    const float t = fmaf(pcv[m][k], lwin[wi], pcc[m][k]);
+                    acc += (rr >= -(seg - 1)) ? t : 0.f;
+                }
+            }
+            st[a.ring_off[0] + pmod(q, a.ring_len[0]) * g.Hp + o] = acc / (1.f + fabsf(acc));
+        }
+    }
+}
+
 // set the sample window after the state was zeroed: softmax = padding class Q/2 (dswnv.py:308) with the caller's seed
 // class in the newest slot; Laplace = the caller's seed samples in the newest seg slots (cswnv_shift1.py:300-334)
 __global__ void step_seed_kernel(const StArgs a) {
@@ -654,6 +775,9 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
         else if (solo) hipLaunchKernelGGL(rowvec_kernel<1>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
         else hipLaunchKernelGGL(rowvec_kernel<8>, dim3(rows, by), dim3(64), 0, st, a, w_off, ldw, b_off, rows, nin, x_off, y_off, relu);
     };
+    // Laplace heads of up to 16 rows over up to 512 inputs, K <= 8 taps, <= 1 024 input-layer elements: the prefetching tail
+    const bool fast_tail = g.kind == SWN_KIND_LAPLACE && g.NO <= 16 && g.O1p <= 512 && g.K <= 8 && g.H * g.seg <= 1024 &&
+                           g.seg <= 16 && a.WN <= 32;
     const int total = a.n_pro + n_steps;
     for (int it = 0; it < total; ++it) {
         // prologue positions and the very first generation step launch their own input layer; later steps
@@ -667,7 +791,10 @@ extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, co
         rowvec(g.S, a.y.wsk, g.L * g.Hp, a.y.bsk, g.L * g.Hp, a.o_hcat, a.o_skip, 1);
         rowvec(g.O1, a.y.w1, g.Sp, a.y.b1, g.Sp, a.o_skip, a.o_o1, 1);
         if (a.o2_by_rowvec) rowvec(g.NO, a.y.w2, g.O1p, a.y.b2, g.O1p, a.o_o1, a.o_o2, 0);
-        if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(256), 0, st, a, it);
+        if (fast_tail) {
+            if (g.H * g.seg <= 256) hipLaunchKernelGGL(step_tail_laplace_kernel<1>, dim3(batch), dim3(256), 0, st, a, it);
+            else hipLaunchKernelGGL(step_tail_laplace_kernel<4>, dim3(batch), dim3(256), 0, st, a, it);
+        } else if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_LAPLACE>, dim3(batch), dim3(256), 0, st, a, it);
         else hipLaunchKernelGGL(step_tail_kernel<SWN_KIND_SOFTMAX>, dim3(batch), dim3(256), 0, st, a, it);
     }
     return swn_launch_status("swn_decode(stepped)");
