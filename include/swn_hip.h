@@ -280,6 +280,13 @@ int    swn_backward_keep(const swn_net_desc* d, const float* packed_dev, const f
  * layer, the dilated conv as a bf16-operand GEMM followed by an element-wise gate kernel (instead of the fused exact-fp32
  * layer kernel) and keeps every layer's gate pre-activations in that buffer; the backward reads them instead of
  * recomputing them. */
+/* BL6 class (swn_backward_bf16's geometries) with SWN_PRECISION_BF16 and no mask between layers (drop_h_host[l] == NULL for
+ * l < L-1; with dilation_repeat == 1 the reference's only hidden-state mask lands on the last layer's output, which nothing
+ * reads - cswnv_shift1.py:211-217): both calls take a fused path instead - masked conditioning and in_x products as bf16
+ * time-major rows from one tiled GEMM, the bf16 layer kernels of swn_forward_bf16 reading those rows, and the fused per-layer
+ * backward of swn_backward_bf16 handing back their gradients for the two in_x contractions.  swn_drop_fused_path() tells
+ * which path a (batch, n_frames, drop_h_host) takes in that mode: 1 fused, 0 the generic chain. */
+int    swn_drop_fused_path(const swn_net_desc* d, int batch, int n_frames, const float* const* drop_h_host);
 size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_forward_drop(const swn_net_desc* d, const float* packed_dev, const float* fe_work_dev, const void* audio_dev,
                         int batch, int n_frames, const float* drop_x_dev, const float* const* drop_h_host,

@@ -81,6 +81,7 @@ SIGNATURES = {
     "swn_backward_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_backward": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                              c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
+    "swn_drop_fused_path": (c_int, [POINTER(NetDesc), c_int, c_int, c_void_p]),
     "swn_forward_drop_work_floats": (c_size_t, [POINTER(NetDesc), c_int, c_int]),
     "swn_forward_drop": (c_int, [POINTER(NetDesc), c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p, c_void_p, c_int, c_void_p]),

@@ -95,6 +95,8 @@ struct BwArgs {
     const unsigned short* wrec;      // [L][8 mt][4 ks][64 lanes][8]  Wd, rows permuted (chan_of)
     const unsigned short* wdg;       // [L+1][4 mt][12 ks][64 lanes][8]  image c: [Wd_c^T over (tap, o2) | Wsk_{c-1}^T], rows permuted
     float* dcond;                    // (B, Tf, N)
+    const unsigned short* gx16;      // dropout mode (GX kernels): sample-rate in_x products [B][Tp][L*128] bf16 in place of cond ...
+    unsigned short* dgx16;           // ... and their gradients [L][B][Tp][128] bf16 in place of dcond / g w_up
     float* gP;                       // gradient of the packed parameters
     int B, Tf, Tp, U, N, L, coff;
     int dil[SWN_MAXL];
@@ -142,7 +144,10 @@ constexpr int BW_LDS = LDS_REC + LDS_DG + 4 * (256 + 128 + 128 + 128);
 // the input layer spill in the whole-frame form (390 -> 244 us at 64 x 16 500).
 template <bool HALF> struct BwShape { static constexpr int NM = HALF ? 2 : 4, THREADS = HALF ? 768 : 512; };
 
-template <int MODE, bool HALF>
+// GX (dropout mode, aux_drop at sample rate: cswnv_shift1.py:194-195): the in_x products of a position are an operand (one
+// bf16 row of a.gx16 per position) instead of w_up[j] * cond[f] + bx, and their gradient leaves as bf16 rows (a.dgx16) for
+// the two in_x GEMMs of the caller instead of being reduced to d cond / g w_up here.
+template <int MODE, bool HALF, bool GX = false>
 __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kernel(const BwArgs a, const int l, const int dil,
                                                                                  const int dil_up, const int n_units, const int Fu) {
     constexpr int NM = BwShape<HALF>::NM, THREADS = BwShape<HALF>::THREADS;
@@ -179,6 +184,9 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
     const __amdgpu_buffer_rsrc_t reo = make_rsrc(a.E[l & 1], lstride * 4);             // E_l: written
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
     const __amdgpu_buffer_rsrc_t rau = make_rsrc(a.audio, (size_t)a.B * a.Tp * 4);
+    const unsigned gx_row = (unsigned)a.L * 256u;                        // bytes of one position's in_x products
+    const __amdgpu_buffer_rsrc_t rgx = make_rsrc(a.gx16, GX ? (size_t)a.B * a.Tp * gx_row : 0);
+    const __amdgpu_buffer_rsrc_t rgo = make_rsrc(GX && MODE != 2 ? a.dgx16 + (size_t)l * lstride * 2 : nullptr, GX && MODE != 2 ? lstride * 4 : 0);
     const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_d = (unsigned)(n * 128 + 8 * g) * 2u;
     const unsigned lane_e = (unsigned)(n * H + 8 * g) * 4u;              // fp32 [t][64]: channels 8g.. of position n
     const unsigned dil_bytes = (unsigned)dil * H * 2u, dilu_bytes = (unsigned)dil_up * 256u;
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
         const int ts = s > 0 ? s : 0;
         int te = s + a.U; te = te < a.Tp ? te : a.Tp;
         const int jj0 = ts - s;
-        float4 cz[NM], cc[NM];
-        if (MODE != 2) {
+        float4 cz[NM] = {}, cc[NM] = {};
+        if (MODE != 2 && !GX) {
             const int fc = f < a.Tf - 1 ? f : a.Tf - 1;
             const unsigned off = (unsigned)((b * a.Tf + fc) * a.N + l * 128 + 8 * g) * 4u + chb * 4u;
 #pragma unroll
@@ -296,6 +304,14 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
                         D[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, du[ks], D[m], 0, 0, 0);
                     }
             }
+            // dropout mode: the in_x products of position t (runs of 8 channels, gate | candidate) are requested here, where the
+            // twelve B fragments of the d h GEMM have just died: with the chunk's other loads they do not fit 168 registers
+            u32x4 gqz[NM / 2], gqc[NM / 2];
+            if (GX && MODE != 2) {
+                const unsigned og = ok ? (pos + n) * gx_row + (unsigned)l * 256u + (chb + 8u * g) * 2u : OOB;
+#pragma unroll
+                for (int hlf = 0; hlf < NM / 2; ++hlf) { gqz[hlf] = ld_u4(rgx, og + 64u * hlf); gqc[hlf] = ld_u4(rgx, og + 128u + 64u * hlf); }
+            }
             if (MODE == 2) {                       // input layer: h_0 = softsign(pre), pre = cb + [t >= 1](cv0 x(t-1) + cc0) + cv1 x(t) + cc1
                 const float m0 = t >= 1 ? 1.f : 0.f;
 #pragma unroll
@@ -339,9 +355,9 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
                     }
             }
             // ---- gates and their derivatives (fp32)
-            const float wu = wus[jj0 + (t0 - ts) + n];
+            const float wu = GX ? 0.f : wus[jj0 + (t0 - ts) + n];
             float pw = 0.f;
-            unsigned dav[2][2 * NM];
+            unsigned dav[2][2 * NM], dgv[2][2 * NM];
             f32x4 eout[NM];
             // the wave's own channels of h(t): tap-1 fragment 2 + (tile >> 1)
             const u32x4 hwa = __builtin_bit_cast(u32x4, x[2]), hwb = __builtin_bit_cast(u32x4, x[3]);
@@ -354,10 +370,15 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
                 const float bzv[4] = {bz4.x, bz4.y, bz4.z, bz4.w}, bcv[4] = {bc4.x, bc4.y, bc4.z, bc4.w};
                 u32x4 hw;
                 if (HALF) hw = mb ? hwb : hwa; else hw = (m >> 1) ? hwb : hwa;
-                float daz[4], dac[4];
+                float daz[4], dac[4], dxz[4], dxc[4];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float gz = fmaf(wu, czv[r], bzv[r]), gc = fmaf(wu, ccv[r], bcv[r]);
+                    float gz, gc;
+                    if (GX) {
+                        const unsigned uz = gqz[m >> 1][(m & 1) * 2 + (r >> 1)], uc = gqc[m >> 1][(m & 1) * 2 + (r >> 1)];
+                        gz = __builtin_bit_cast(float, (r & 1) ? (uz & 0xffff0000u) : (uz << 16));
+                        gc = __builtin_bit_cast(float, (r & 1) ? (uc & 0xffff0000u) : (uc << 16));
+                    } else { gz = fmaf(wu, czv[r], bzv[r]); gc = fmaf(wu, ccv[r], bcv[r]); }
                     const float az = acc[m][r], ac = acc[NM + m][r];
                     const float z = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(K_SIG * gz * az));
                     const float q = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(K_TANH * gc * ac));
@@ -371,12 +392,19 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
                     daz[r] = dz * gz; dac[r] = dc * gc;
                     const float gxz = dz * az, gxc = dc * ac;            // d in_x products
                     eout[m][r] = dh * z;                                  // highway carry
-                    dca[0][m][r] = fmaf(wu, gxz, dca[0][m][r]); dca[1][m][r] = fmaf(wu, gxc, dca[1][m][r]);
                     gbx[0][m][r] += gxz; gbx[1][m][r] += gxc;
-                    pw = fmaf(gxz, czv[r], pw); pw = fmaf(gxc, ccv[r], pw);
+                    if (GX) { dxz[r] = gxz; dxc[r] = gxc; }
+                    else {
+                        dca[0][m][r] = fmaf(wu, gxz, dca[0][m][r]); dca[1][m][r] = fmaf(wu, gxc, dca[1][m][r]);
+                        pw = fmaf(gxz, czv[r], pw); pw = fmaf(gxc, ccv[r], pw);
+                    }
                 }
                 dav[0][m * 2] = pack2(daz[0], daz[1]); dav[0][m * 2 + 1] = pack2(daz[2], daz[3]);
                 dav[1][m * 2] = pack2(dac[0], dac[1]); dav[1][m * 2 + 1] = pack2(dac[2], dac[3]);
+                if (GX) {
+                    dgv[0][m * 2] = pack2(dxz[0], dxz[1]); dgv[0][m * 2 + 1] = pack2(dxz[2], dxz[3]);
+                    dgv[1][m * 2] = pack2(dxc[0], dxc[1]); dgv[1][m * 2 + 1] = pack2(dxc[2], dxc[3]);
+                }
             }
             // ---- stores: da (bf16, [t][128]) and E_l (fp32, [t][64])
             {
@@ -387,6 +415,10 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
                     for (int hlf = 0; hlf < NM / 2; ++hlf) {
                         const u32x4 v = {dav[q][4 * hlf], dav[q][4 * hlf + 1], dav[q][4 * hlf + 2], dav[q][4 * hlf + 3]};
                         __builtin_amdgcn_raw_buffer_store_b128(v, rdo, so + 128u * q + 64u * hlf, 0, 0);
+                        if (GX) {
+                            const u32x4 vg = {dgv[q][4 * hlf], dgv[q][4 * hlf + 1], dgv[q][4 * hlf + 2], dgv[q][4 * hlf + 3]};
+                            __builtin_amdgcn_raw_buffer_store_b128(vg, rgo, so + 128u * q + 64u * hlf, 0, 0);
+                        }
                     }
                 const unsigned eo = ok ? pos * 256u + lane_e + chb * 4u : OOB;
 #pragma unroll
@@ -396,11 +428,13 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
             }
             // g w_up[jj] += sum_o2 dgx[o2][t] * cond[f][o2]: finish the sum over the four lane groups (and, through the LDS
             // accumulator, over the two waves of a frame)
-            pw += __shfl_xor(pw, 16);
-            pw += __shfl_xor(pw, 32);
-            if (g == 0 && ok) atomicAdd(gwl + jj0 + (t0 - ts) + n, pw);
+            if (!GX) {
+                pw += __shfl_xor(pw, 16);
+                pw += __shfl_xor(pw, 32);
+                if (g == 0 && ok) atomicAdd(gwl + jj0 + (t0 - ts) + n, pw);
+            }
         }
-        if (MODE != 2) {
+        if (MODE != 2 && !GX) {
             // dcond[b][f][l*128 + o2] = sum over the frame's positions
 #pragma unroll
             for (int q = 0; q < 2; ++q)
@@ -456,8 +490,10 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
         }
         return;
     }
-    if (tid < 128) atomicAdd(a.gP + a.y.bx + (size_t)l * 128 + tid, gbl[tid]);
-    else if (tid - 128 < a.U) atomicAdd(a.gP + a.y.wup + tid - 128, gwl[tid - 128]);
+    // (dropout mode: in_x runs at sample rate on a conditioning that already holds b_up, its bias gradient is that of the
+    //  raw bias - section bxr, csrc/swn_geom.hpp - and g w_up comes from the caller's xm backward)
+    if (tid < 128) atomicAdd(a.gP + (GX ? a.y.bxr : a.y.bx) + (size_t)l * 128 + tid, gbl[tid]);
+    else if (!GX && tid - 128 < a.U) atomicAdd(a.gP + a.y.wup + tid - 128, gwl[tid - 128]);
 }
 
 // ---- weight gradients, all of them in one launch --------------------------------------------------------------------------
@@ -465,6 +501,7 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
 //   dil_h of layer l    A = da_l            X(t) = [h_l(t - d_l) ; h_l(t)]
 //   out_skip, 3 jobs    A = dskip           X(t) = [h_{2q+1}(t) ; h_{2q+2}(t)]        (columns 128q.. of the 128 x 384 matrix)
 //   out_1               A = d out_1         X(t) = relu(skip)(t)
+//   in_x of layer l, dropout mode (second launch): A = d gx_l, X(t) = 128 channels of the masked conditioning xm16(t)
 // Workgroup = (time split, job); per step a 32-position tile of both operands is staged in LDS in the layout it has in
 // HBM ([t][128] bf16, 16-byte chunks XOR-swizzled against bank conflicts) and the MFMA fragments - which want the
 // reduction axis t inside a lane - are read with the transposing ds_read_b64_tr_b16.  Wave w owns rows 32w..32w+31 of the
@@ -476,6 +513,7 @@ struct WJob {
     const unsigned short* X0; const unsigned short* X1;     // left / right 64 columns of X: rows of rs0 / rs1 elements
     int rs0, rs1, sh0, sh1;            // row strides (elements) and time shifts (X0 is read at t - sh0, zero before the start)
     float* out; int ld; float* bias;   // G (row stride ld), bias (may be null)
+    int ncols;                         // columns of the job that exist in G (128, less in the last column block of in_x)
 };
 constexpr int WG_MAXJOBS = SWN_MAXL + 4;
 struct WgArgs { WJob job[WG_MAXJOBS]; int B, Tp; };
@@ -557,7 +595,8 @@ __global__ __launch_bounds__(256) void bl6_wgrad_kernel(const WgArgs a, const in
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * (2 * w + mi) + 4 * g + r;
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) atomicAdd(jb.out + (size_t)row * jb.ld + 16 * nt + n, acc[mi][nt][r]);
+            for (int nt = 0; nt < 8; ++nt)
+                if (16 * nt + n < jb.ncols) atomicAdd(jb.out + (size_t)row * jb.ld + 16 * nt + n, acc[mi][nt][r]);
             if (n == 0 && jb.bias) atomicAdd(jb.bias + row, accb[mi][r]);
         }
 }
@@ -781,9 +820,9 @@ __global__ __launch_bounds__(HB_THREADS, 1) void bl6_head_bwd_kernel(const HbArg
     }
 }
 
-template <int MODE, bool HALF>
+template <int MODE, bool HALF, bool GX>
 int launch_layer_h(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, hipStream_t st) {
-    auto kern = bl6_layer_bwd_kernel<MODE, HALF>;
+    auto kern = bl6_layer_bwd_kernel<MODE, HALF, GX>;
     static bool attr_done = false;                                // per instantiation; the attribute is per function
     if (!attr_done) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, BW_LDS) != hipSuccess)
@@ -797,11 +836,20 @@ int launch_layer_h(const BwArgs& a, int l, int dil, int dil_up, int n_units, int
     return SWN_OK;
 }
 // half-frame units while the frames alone cannot fill the chip's wave slots twice over (see BwShape)
-template <int MODE>
+template <int MODE, bool GX = false>
 int launch_layer(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, hipStream_t st) {
     // (the last launch carries 64 more accumulators per lane for the input layer: always in halves, or it spills)
-    return (MODE == 2 || n_units < 2 * 2048) ? launch_layer_h<MODE, true>(a, l, dil, dil_up, n_units, Fu, st)
-                                             : launch_layer_h<MODE, false>(a, l, dil, dil_up, n_units, Fu, st);
+    // (dropout mode: whole frames at every size - the half-frame form of the GX kernels spills, 97 registers at 168)
+    if constexpr (GX) return launch_layer_h<MODE, false, true>(a, l, dil, dil_up, n_units, Fu, st);
+    else return (MODE == 2 || n_units < 2 * 2048) ? launch_layer_h<MODE, true, false>(a, l, dil, dil_up, n_units, Fu, st)
+                                                  : launch_layer_h<MODE, false, false>(a, l, dil, dil_up, n_units, Fu, st);
+}
+// fp32 [rows][ld] -> transposed bf16 [cols (padded to dcols rows... )]: dst[c][r] = src[r][c] for c < cols, zero rows c >= cols
+__global__ void rowsT_to_bf16_kernel(const float* __restrict__ src, int ld, int rows, int cols, int drows, unsigned short* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)drows * rows) return;
+    const int c = (int)(e / rows), r = (int)(e - (size_t)c * rows);
+    dst[e] = c < cols ? f2bf(src[(size_t)r * ld + c]) : (unsigned short)0;
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -824,12 +872,21 @@ size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp) {
     return al256((size_t)g.L * LDS_REC) + al256((size_t)(g.L + 1) * LDS_DG) + IMG_WSK + 2 * IMG_W1 + IMG_W2T +
            (size_t)(g.L + 5) * row;
 }
+// dropout mode: + d gx of every layer [L][B][Tp][128] bf16 and the transposed in_x image [A0x][L*128] bf16
+size_t swn_bl6_bwd_drop_scratch_bytes(const SwnGeom& g, int B, long Tp) {
+    return swn_bl6_bwd_scratch_bytes(g, B, Tp) + al256((size_t)g.L * B * Tp * 256) + al256((size_t)swn_a0x(&g) * g.L * 128 * 2);
+}
+int swn_bf16g_plain(const unsigned short* A, int M, const unsigned short* src, size_t blk_stride, size_t src_bytes, int KB, int nblk,
+                    int Tp, int B, const float* bias, unsigned short* out_bf, int out_ld, float* out_f, int NO, hipStream_t st);
 
 // The whole stack backward behind d raw: head (out_2, out_1, skip), the gated layers, the input layer.  Fills dcond and every
 // sample-rate section of gpacked (zeroed by the caller): w2 b2 w1 b1 wsk bsk wd bd bx wup cb cv cc.
+// Dropout mode (gx16 != null: the forward was swn_bl6_drop_forward; cond and dcond are not used, scratch holds
+// swn_bl6_bwd_drop_scratch_bytes): fills wx and bxr instead of bx / wup, and dxm (B, A0, Tx) fp32 = in_x^T d gx, the
+// gradient wrt the masked conditioning (the caller's xm backward turns it into d C, g w_up, g b_up).
 int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
                       const void* hs_bf16, const float* grad_out, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
-                      long Tp, hipStream_t st) {
+                      long Tp, hipStream_t st, const unsigned short* gx16, const unsigned short* xm16, float* dxm) {
     BwArgs a;
     a.P = packed; a.y = y; a.cond = cond; a.audio = audio; a.hs = reinterpret_cast<const unsigned short*>(hs_bf16);
     unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
@@ -847,6 +904,9 @@ int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed,
     unsigned short* do1 = reinterpret_cast<unsigned short*>(p); p += row;
     a.dsk = dsk;
     a.da = reinterpret_cast<unsigned short*>(p);                 // L buffers of B*Tp*256 bytes, contiguous (no padding)
+    p = reinterpret_cast<unsigned char*>(scratch) + swn_bl6_bwd_scratch_bytes(g, B, Tp);
+    a.gx16 = gx16; a.dgx16 = gx16 ? reinterpret_cast<unsigned short*>(p) : nullptr;
+    unsigned short* wxt = reinterpret_cast<unsigned short*>(p + al256((size_t)g.L * B * Tp * 256));      // dropout mode only
     a.wrec = wrec; a.wdg = wdg;
     a.dcond = dcond; a.gP = gpacked;
     a.B = B; a.Tf = n_frames; a.Tp = (int)Tp; a.U = g.U; a.N = g.N; a.L = g.L; a.coff = g.seg;
@@ -880,7 +940,10 @@ int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed,
     const int n_units = B * Fu;
     int rc = SWN_OK;
     for (int l = g.L - 1; l >= 0 && rc == SWN_OK; --l) {
-        if (l == g.L - 1) rc = launch_layer<0>(a, l, g.dil[l], 1, n_units, Fu, st);
+        if (gx16) {
+            if (l == g.L - 1) rc = launch_layer<0, true>(a, l, g.dil[l], 1, n_units, Fu, st);
+            else rc = launch_layer<1, true>(a, l, g.dil[l], g.dil[l + 1], n_units, Fu, st);
+        } else if (l == g.L - 1) rc = launch_layer<0>(a, l, g.dil[l], 1, n_units, Fu, st);
         else rc = launch_layer<1>(a, l, g.dil[l], g.dil[l + 1], n_units, Fu, st);
     }
     if (rc == SWN_OK) rc = launch_layer<2>(a, -1, 1, g.dil[0], n_units, Fu, st);
@@ -894,15 +957,41 @@ int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed,
         for (int l = 0; l < g.L; ++l) {
             const unsigned short* hl = a.hs + (size_t)l * lstride;
             wa.job[nj++] = WJob{a.da + (size_t)l * lstride * 2, hl, hl, H, H, g.dil[l], 0, gpacked + y.wd + (size_t)l * 128 * 128, 128,
-                                gpacked + y.bd + (size_t)l * 128};
+                                gpacked + y.bd + (size_t)l * 128, 128};
         }
         for (int qq = 0; qq < g.L / 2; ++qq)
             wa.job[nj++] = WJob{dsk, a.hs + (size_t)(2 * qq + 1) * lstride, a.hs + (size_t)(2 * qq + 2) * lstride, H, H, 0, 0,
-                                gpacked + y.wsk + 128 * qq, g.L * g.Hp, qq == 0 ? gpacked + y.bsk : nullptr};
-        wa.job[nj++] = WJob{do1, s1, s1 + H, 128, 128, 0, 0, gpacked + y.w1, g.Sp, gpacked + y.b1};
+                                gpacked + y.wsk + 128 * qq, g.L * g.Hp, qq == 0 ? gpacked + y.bsk : nullptr, 128};
+        wa.job[nj++] = WJob{do1, s1, s1 + H, 128, 128, 0, 0, gpacked + y.w1, g.Sp, gpacked + y.b1, 128};
         const int tiles_per_b = (int)((Tp + 31) / 32), n_tiles = B * tiles_per_b;
         const int split = n_tiles < 96 ? n_tiles : 96;
         hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split, nj), dim3(256), 0, st, wa, tiles_per_b, n_tiles);
+        if (gx16) {
+            // g in_x.W[l][o][c] = sum_t d gx_l[t][o] xm[t][c] in column blocks of 128 conditioning channels (g b_inx: the layer kernels)
+            const int A0x = swn_a0x(&g), ncb = (g.A0 + 127) / 128;
+            nj = 0;
+            for (int l = 0; l < g.L; ++l)
+                for (int cb = 0; cb < ncb; ++cb) {
+                    // (a last block of 32 or 64 columns past A0x reads the neighbouring row's first channels: finite values, never stored)
+                    wa.job[nj++] = WJob{a.dgx16 + (size_t)l * lstride * 2, xm16 + 128 * cb, xm16 + 128 * cb + 64, A0x, A0x, 0, 0,
+                                        gpacked + y.wx + (size_t)l * 128 * g.A0p + 128 * cb, g.A0p, nullptr,
+                                        g.A0 - 128 * cb < 128 ? g.A0 - 128 * cb : 128};
+                    if (nj == WG_MAXJOBS || (l == g.L - 1 && cb == ncb - 1)) {
+                        hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split, nj), dim3(256), 0, st, wa, tiles_per_b, n_tiles);
+                        nj = 0;
+                    }
+                }
+        }
+    }
+    if (gx16) {
+        // dxm[b][c][u] = sum_{l,o} in_x[l].W[o][c] d gx_l[b][u][o]: A = the transposed matrices [c][l*128 + o], k = L blocks of 128
+        const int A0x = swn_a0x(&g);
+        hipLaunchKernelGGL(rowsT_to_bf16_kernel, dim3((unsigned)(((size_t)A0x * g.L * 128 + 255) / 256)), dim3(256), 0, st,
+                           packed + y.wx, g.A0p, g.L * 128, g.A0, A0x, wxt);
+        const size_t lstride2 = (size_t)B * Tp * 128;
+        const int rcg = swn_bf16g_plain(wxt, g.A0, a.dgx16, lstride2, (size_t)g.L * lstride2 * 2, 128, g.L, (int)Tp, B, nullptr,
+                                        nullptr, 0, dxm, g.A0, st);
+        if (rcg < 0) return rcg;
     }
     return swn_launch_status("swn_backward_bf16");
 }

@@ -160,6 +160,21 @@ static inline __host__ int swn_a0x(const SwnGeom* g) { return (g->A0 + 31) & ~31
 // dropout (H a multiple of 64): smaller nets keep the exact-fp32 forward, only their contractions of the backward are rounded.
 static inline __host__ bool swn_drop_bf16_forward(const SwnGeom* g) { return g->Hp == g->H && (g->H % 64) == 0; }
 
+// BL6 class, mixed-precision mode, dropout as run.sh trains it (dilation_repeat == 1: the only hidden-state mask lands on the
+// last layer's output, which feeds nothing, so aux_drop is the one mask that acts - cswnv_shift1.py:194-195,211-217): the
+// forward work buffer of the fused path (csrc/swn_stack_bf16.hip: swn_bl6_drop_forward; read back by swn_bl6_bwd_stack).
+// Byte offsets, every section 256-byte aligned.
+struct SwnBl6DropLayout {
+    size_t hs16;       // [L+1][B][Tp][64] bf16 hidden states, time-major
+    size_t wbf;        // fragment-ordered bf16 weights of the layer / head kernels (swn_pack_bf16's image)
+    size_t wx16;       // [L*128][A0x] bf16: in_x matrices, zero columns A0..A0x
+    size_t xm16;       // [B][Tx][A0x] bf16: masked, upsampled conditioning, time-major
+    size_t gx16;       // [B][Tp][L*128] bf16: sample-rate in_x products, bias included
+    size_t total;
+};
+bool swn_bl6_drop_supported(const SwnGeom& g, int B, long Tp, int n_frames, const float* const* drop_h);   // csrc/swn_stack_bf16.hip
+SwnBl6DropLayout swn_bl6_drop_layout(const SwnGeom& g, int B, long Tp);
+
 // number of state_dict tensors in reference order (shallow_wavenet_amd/config.py param_shapes)
 static inline __host__ int swn_tensor_count(const SwnGeom* g) {
     return 2 + 2 * g->auxl + 2 + (g->conv2d ? 2 : 0) + (g->wav ? 2 : 0) + 2 + 6 * g->L + 4;

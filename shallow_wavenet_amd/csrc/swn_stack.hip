@@ -302,6 +302,9 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
 // sample-rate in_x of every layer over the masked conditioning (csrc/swn_train.hip: generic time GEMM)
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
                           int B, int Tx, int Tp, hipStream_t st);
+// BL6 class, mixed-precision mode, aux_drop the only mask that acts: the fused path (csrc/swn_stack_bf16.hip)
+int swn_bl6_drop_forward(const SwnGeom& g, const float* packed, const float* C, const float* audio, const float* drop_x,
+                         int batch, int n_frames, void* work, float* out, hipStream_t st);
 
 namespace {
 
@@ -330,6 +333,12 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
     }
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported
+    if (drop && !hs && swn_call_mode() == SWN_PRECISION_BF16 && swn_bl6_drop_supported(g, batch, Tp, n_frames, drop_h)) {
+        size_t fe_off = (size_t)g.n_aux;                         // frame-rate activations: scaled | conv_aux layers
+        for (int i = 0; i + 1 < g.auxl; ++i) fe_off += g.aux_cout[i];
+        return swn_bl6_drop_forward(g, packed, fe_work + fe_off * (size_t)batch * n_frames, reinterpret_cast<const float*>(audio),
+                                    drop_x, batch, n_frames, work, out, st);
+    }
     const size_t hs_floats = r64((size_t)batch * (g.L + 1) * g.H * Tp);
     float* hbuf = hs ? hs : work;
     float* skipb = work + hs_floats;
@@ -401,6 +410,13 @@ extern "C" int swn_forward(const swn_net_desc* d, const float* packed, const flo
     return forward_impl(d, packed, cond, nullptr, audio, batch, n_frames, nullptr, nullptr, work, out, hs, stream_, "swn_forward");
 }
 
+extern "C" int swn_drop_fused_path(const swn_net_desc* d, int batch, int n_frames, const float* const* drop_h) {
+    SwnGeom g;
+    if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1 || g.kind != SWN_KIND_LAPLACE) return 0;
+    const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
+    return Tp >= 1 && swn_bl6_drop_supported(g, batch, Tp, n_frames, drop_h) ? 1 : 0;
+}
+
 extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
     const size_t base = swn_forward_work_floats(d, batch, n_frames);
@@ -409,8 +425,10 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
     const int coff = g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     // xm | gx | (mixed-precision forward) gate pre-activations of every layer | masked input of one layer
-    return base + r64((size_t)batch * swn_a0x(&g) * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
-           (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
+    const size_t chain = base + r64((size_t)batch * swn_a0x(&g) * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
+                         (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
+    const size_t fused = g.bl6 ? (swn_bl6_drop_layout(g, batch, Tp).total + 3) / 4 : 0;      // the fused BL6 path's own layout
+    return chain > fused ? chain : fused;
 }
 
 extern "C" int swn_forward_drop(const swn_net_desc* d, const float* packed, const float* fe_work, const void* audio,

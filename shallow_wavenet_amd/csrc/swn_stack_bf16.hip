@@ -63,6 +63,7 @@ struct BfArgs {
     float* out;                  // (B, NO, Tp)
     int B, Tf, Tp, U, N, L, seg, NO, coff;
     size_t off_wd, off_wsk, off_w1, off_w2;   // element offsets into wbf
+    const unsigned short* gx16;  // dropout mode: sample-rate in_x products (bias included) [B][Tp][L*128] bf16, else null
 };
 
 // ---- fp32 packed -> fragment-ordered bf16:  dst[(mt*KS + ks)*64 + lane][8] = W[16mt + (lane&15)][32ks + 8(lane>>4) + j]
@@ -153,6 +154,7 @@ struct CondOps {
     float4 cz[4], cc[4];                // hoisted in_x rows of this lane's 16 channels (gate | candidate)
     float wu;                           // upsampler tap of position t
 };
+struct GxOps { u32x4 z[2], c[2]; };     // dropout mode: the in_x products of position t, channels 8g.. / 32 + 8g.. (gate | candidate), bf16
 constexpr int NSLOT = 8;                // B-fragment ring (AccVGPRs): chunk k+7 is fetched while chunk k is computed:
                                         // ~7 KB of HBM reads in flight per wave, what the latency-bandwidth product needs
 constexpr float K_SIG = -1.44269504f;   // sigmoid(x) = 1 / (1 + 2^(K_SIG x))
@@ -203,7 +205,10 @@ __device__ __forceinline__ void mfma_next(f32x4 (&acc)[8], const bf16x8 (&A)[8][
 // the epilogue is kept off the vector ALU: chunk arithmetic is scalar, addresses are 32-bit buffer
 // offsets, the sigmoid/tanh scale factors are folded into the conditioning constants, and saturation
 // needs no clamps (2^x -> inf -> rcp -> 0 gives the exact limits).
-template <bool FAST>   // FAST: seg == 1 and U >= 16, conditioning rows prefetched through the buffer path
+// CM: where the conditioning comes from.  0: hoisted rows, any seg (plain loads)   1: seg == 1 and U >= 16, hoisted rows
+// prefetched through the buffer path   2: dropout mode (aux_drop acts at sample rate, cswnv_shift1.py:194-195): the in_x
+// products themselves, one bf16 row per position (a.gx16, made by a GEMM over the masked conditioning)
+template <int CM>
 __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, const int l, const int dil, const int n_chunks) {
     __shared__ __attribute__((aligned(16))) float cst[2 * 128];      // bd[128] | prescaled bx[128] of this layer
     const int tid = threadIdx.x, lane = tid & 63;
@@ -224,6 +229,8 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
     const __amdgpu_buffer_rsrc_t rh = make_rsrc(a.hs + (size_t)l * lstride, lstride * 2);
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(a.cond, (size_t)a.B * a.Tf * a.N * 4);
     const __amdgpu_buffer_rsrc_t ru = make_rsrc(a.P + a.y.wup, (size_t)a.U * 4);
+    const unsigned gx_row = (unsigned)a.L * 256u;                    // bytes of one position's in_x products
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(a.gx16, CM == 2 ? (size_t)a.B * a.Tp * gx_row : 0);
     unsigned short* hnext = a.hs + (size_t)(l + 1) * lstride;
     const int chunks_per_b = (a.Tp + 15) / 16;
     const unsigned lane_h = (unsigned)(n * H + 8 * g) * 2u, lane_c = (unsigned)(8 * g) * 4u;
@@ -259,6 +266,16 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
         }
     };
 
+    auto fetch_g = [&](int c, GxOps& k) {                            // dropout mode: in_x products of chunk c
+        c = c < n_chunks ? c : n_chunks - 1;
+        const int b = c / chunks_per_b, t0 = (c - b * chunks_per_b) * 16, t = t0 + n;
+        const unsigned off = t < a.Tp ? (unsigned)(b * a.Tp + t) * gx_row + (unsigned)l * 256u + 16u * g : OOB;
+        k.z[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+        k.z[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, off + 64u, 0, 0);
+        k.c[0] = __builtin_amdgcn_raw_buffer_load_b128(rg, off + 128u, 0, 0);
+        k.c[1] = __builtin_amdgcn_raw_buffer_load_b128(rg, off + 192u, 0, 0);
+    };
+
     // per-lane epilogue constants of its 16 channels stay in registers (LDS reads inside the epilogue stalled it)
     f32x4 kbd[8];                      // dil_h bias of accumulator tile mt: the C operand of its first MFMA
     float4 kbxz[4], kbxc[4];
@@ -273,10 +290,12 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
     const int W = gridDim.x * 4;                                     // every wave walks its own chunk sequence
     int c = blockIdx.x * 4 + w;
     if (c >= n_chunks) return;
-    constexpr bool fast = FAST;
+    constexpr bool fast = CM == 1, gxm = CM == 2;
     BFrag ring[NSLOT];
     CondOps cnd[2];
+    GxOps gxo[2];
     if (fast) fetch_c(c, cnd[0]);
+    if (gxm) fetch_g(c, gxo[0]);
 #pragma unroll
     for (int u = 0; u < NSLOT - 1; ++u) fetch_b(c + u * W, ring[u]);
     // one round = NSLOT chunks with static ring slots.  The first round is peeled (called once ahead of the
@@ -287,9 +306,11 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
         for (int u = 0; u < NSLOT; ++u) {
             if (c >= n_chunks) return false;
             if (fast) fetch_c(c + W, cnd[(u + 1) & 1]);
+            if (gxm) fetch_g(c + W, gxo[(u + 1) & 1]);
             fetch_b(c + (NSLOT - 1) * W, ring[(u + NSLOT - 1) % NSLOT]);
             const BFrag& cur = ring[u];
             const CondOps& k = cnd[u & 1];
+            const GxOps& kg = gxo[u & 1];
             const int b = c / chunks_per_b, t = (c - b * chunks_per_b) * 16 + n;
             f32x4 acc[8];                                   // = bd + Wd . [h(t-dil) ; h(t)]
             mfma_first(acc, A, cur.b[0], kbd);
@@ -303,7 +324,15 @@ __global__ __launch_bounds__(256, 1) void bf16_layer_kernel(const BfArgs a, cons
                 const int ch = chan_of(m, g, 0);
                 const float4 bxz = kbxz[m], bxc = kbxc[m];
                 float gz[4] = {bxz.x, bxz.y, bxz.z, bxz.w}, gc[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
-                if (fast) {
+                if (gxm) {                         // the bias is part of the products
+                    const u32x4 wz = kg.z[m >> 1], wc = kg.c[m >> 1];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const unsigned uz = wz[(m & 1) * 2 + (r >> 1)], uc = wc[(m & 1) * 2 + (r >> 1)];
+                        gz[r] = K_SIG * __builtin_bit_cast(float, (r & 1) ? (uz & 0xffff0000u) : (uz << 16));
+                        gc[r] = K_TANH * __builtin_bit_cast(float, (r & 1) ? (uc & 0xffff0000u) : (uc << 16));
+                    }
+                } else if (fast) {
                     const float czv[4] = {k.cz[m].x, k.cz[m].y, k.cz[m].z, k.cz[m].w};
                     const float ccv[4] = {k.cc[m].x, k.cc[m].y, k.cc[m].z, k.cc[m].w};
 #pragma unroll
@@ -936,6 +965,45 @@ __global__ __launch_bounds__(256, 2) void bf16_head_kernel(const BfArgs a, const
     }
 }
 
+// ---- dropout mode (aux_drop at sample rate) ---------------------------------------------------------------------------
+// xm16[b][u][c] = bf16(drop_x[b][c][u] * (C[b][c][f] * w_up[j] + b_up)),  u + coff = f*U + j   (cswnv_shift1.py:193-195):
+// the masked conditioning as time-major rows, the B operand of the in_x GEMM.  Workgroup = 64 positions x 64 channels: the
+// mask is read along its contiguous axis (positions), transposed through LDS and leaves as 128-byte row segments.
+__global__ __launch_bounds__(256) void xm16_kernel(const float* __restrict__ C, const float* __restrict__ P, size_t wup, size_t bup,
+                                                   const float* __restrict__ drop_x, unsigned short* __restrict__ xm,
+                                                   int A0, int A0x, int Tf, int U, int coff, int Tx) {
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64 * 72];       // [position][64 channels + 8 pad]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int u0 = blockIdx.x * 64, c0 = blockIdx.y * 64, b = blockIdx.z;
+    const int u = u0 + lane;
+    if (u < Tx) {
+        const int tt = u + coff, f = tt / U, j = tt - f * U;
+        const float wu = P[wup + j], bu = P[bup];
+#pragma unroll 4
+        for (int i = 0; i < 16; ++i) {
+            const int c = c0 + 16 * w + i;
+            float v = 0.f;
+            if (c < A0) v = drop_x[((size_t)b * A0 + c) * Tx + u] * fmaf(C[((size_t)b * A0 + c) * Tf + f], wu, bu);
+            tile[lane * 72 + 16 * w + i] = f2bf(v);
+        }
+    }
+    __syncthreads();
+    const int r = tid >> 2, q = tid & 3;                           // position, 16-channel quarter
+    if (u0 + r < Tx && c0 + 16 * q < A0x) {
+        const uint4 v0 = *reinterpret_cast<const uint4*>(tile + r * 72 + 16 * q);
+        const uint4 v1 = *reinterpret_cast<const uint4*>(tile + r * 72 + 16 * q + 8);
+        uint4* dst = reinterpret_cast<uint4*>(xm + ((size_t)b * Tx + u0 + r) * A0x + c0 + 16 * q);
+        dst[0] = v0; dst[1] = v1;
+    }
+}
+// fp32 [rows][ld] (first `cols` of each row) -> bf16 [rows][dcols], zero columns cols..dcols
+__global__ void rows_to_bf16_kernel(const float* __restrict__ src, int ld, int rows, int cols, int dcols, unsigned short* __restrict__ dst) {
+    const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (size_t)rows * dcols) return;
+    const int r = (int)(e / dcols), c = (int)(e - (size_t)r * dcols);
+    dst[e] = c < cols ? f2bf(src[(size_t)r * ld + c]) : (unsigned short)0;
+}
+
 int bf_geom(const swn_net_desc* d, SwnGeom* g) {
     int rc = swn_make_geom(d, g);
     if (rc < 0) return rc;
@@ -967,6 +1035,81 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, co
                       int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep = nullptr);
 size_t swn_bf16g_keep_floats(const SwnGeom& g, int batch, long Tp);
 
+int swn_bf16g_plain(const unsigned short* A, int M, const unsigned short* src, size_t blk_stride, size_t src_bytes, int KB, int nblk,
+                    int Tp, int B, const float* bias, unsigned short* out_bf, int out_ld, float* out_f, int NO, hipStream_t st);
+bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames);                    // csrc/swn_bwd_bl6.hip
+
+namespace {
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+void pack_bl6_images(const SwnGeom& g, const SwnLayout& y, const float* packed, unsigned short* wbf, hipStream_t st) {
+    const BfOffsets o = bf_offsets(g);
+    hipLaunchKernelGGL(pack_wd_kernel, dim3((g.L * 8 * 4 * 512 + 255) / 256), dim3(256), 0, st, packed + y.wd, g.L, wbf + o.wd);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((8 * g.L * 2 * 512 + 255) / 256), dim3(256), 0, st,
+                       packed + y.wsk, g.L * 64, 128, g.L * 64, 8, g.L * 2, wbf + o.wsk);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((8 * 4 * 512 + 255) / 256), dim3(256), 0, st, packed + y.w1, g.Sp, 128, 128, 8, 4, wbf + o.w1);
+    hipLaunchKernelGGL(pack_frag_kernel, dim3((4 * 512 + 255) / 256), dim3(256), 0, st, packed + y.w2, g.O1p, g.NO, 128, 1, 4, wbf + o.w2);
+}
+}  // namespace
+
+// ---- dropout mode of the BL6 class in the mixed-precision mode (SwnBl6DropLayout, csrc/swn_geom.hpp) -------------------------
+// With dilation_repeat == 1 the reference's hidden-state dropout lands on the last layer's output only
+// (cswnv_shift1.py:211-217: (l + 1) % dilation_depth == 0 <=> l = L - 1), which nothing reads: the step is the plain one with
+// the hoisted conditioning replaced by sample-rate in_x products of the masked conditioning.
+bool swn_bl6_drop_supported(const SwnGeom& g, int B, long Tp, int n_frames, const float* const* drop_h) {
+    if (!g.bl6 || g.kind != SWN_KIND_LAPLACE || g.S != 128 || g.NO > 16 || g.L != 6 || !swn_bl6_bwd_supported(g, B, Tp, n_frames)) return false;
+    if (!drop_h) return false;
+    for (int l = 0; l + 1 < g.L; ++l) if (drop_h[l]) return false;           // a mask between layers: the generic chain
+    const size_t npos = (size_t)B * Tp;                                       // seg == 1: Tx == Tp
+    return npos * g.L * 256 < (1ull << 31) && npos * swn_a0x(&g) * 2 < (1ull << 31);
+}
+SwnBl6DropLayout swn_bl6_drop_layout(const SwnGeom& g, int B, long Tp) {
+    SwnBl6DropLayout o;
+    const size_t npos = (size_t)B * Tp;
+    o.hs16 = 0;
+    o.wbf = o.hs16 + al256((size_t)(g.L + 1) * npos * H * 2);
+    o.wx16 = o.wbf + al256(bf_offsets(g).total * 2);
+    o.xm16 = o.wx16 + al256((size_t)g.L * 128 * swn_a0x(&g) * 2);
+    o.gx16 = o.xm16 + al256(npos * swn_a0x(&g) * 2);
+    o.total = o.gx16 + al256(npos * g.L * 256);
+    return o;
+}
+// C: the last conv_aux activation (B, A0, Tf) inside swn_frontend's work buffer; work: SwnBl6DropLayout.total bytes
+int swn_bl6_drop_forward(const SwnGeom& g, const float* packed, const float* C, const float* audio, const float* drop_x,
+                         int batch, int n_frames, void* work, float* out, hipStream_t st) {
+    const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
+    const int Tx = (int)Tp, A0x = swn_a0x(&g);
+    const SwnBl6DropLayout lo = swn_bl6_drop_layout(g, batch, Tp);
+    unsigned char* wb = reinterpret_cast<unsigned char*>(work);
+    unsigned short* wx16 = reinterpret_cast<unsigned short*>(wb + lo.wx16);
+    unsigned short* xm16 = reinterpret_cast<unsigned short*>(wb + lo.xm16);
+    unsigned short* gx16 = reinterpret_cast<unsigned short*>(wb + lo.gx16);
+    BfArgs a;
+    swn_make_layout(&g, &a.y);
+    const BfOffsets o = bf_offsets(g);
+    a.P = packed; a.wbf = reinterpret_cast<const unsigned short*>(wb + lo.wbf); a.cond = nullptr; a.audio = audio;
+    a.hs = reinterpret_cast<unsigned short*>(wb + lo.hs16); a.out = out;
+    a.B = batch; a.Tf = n_frames; a.Tp = (int)Tp; a.U = g.U; a.N = g.N; a.L = g.L; a.seg = g.seg; a.NO = g.NO; a.coff = g.seg;
+    a.off_wd = o.wd; a.off_wsk = o.wsk; a.off_w1 = o.w1; a.off_w2 = o.w2; a.gx16 = gx16;
+    (void)hipGetLastError();
+    pack_bl6_images(g, a.y, packed, reinterpret_cast<unsigned short*>(wb + lo.wbf), st);
+    hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)(((size_t)g.L * 128 * A0x + 255) / 256)), dim3(256), 0, st,
+                       packed + a.y.wx, g.A0p, g.L * 128, g.A0, A0x, wx16);
+    hipLaunchKernelGGL(xm16_kernel, dim3((Tx + 63) / 64, A0x / 64 + (A0x % 64 ? 1 : 0), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
+                       drop_x, xm16, g.A0, A0x, n_frames, g.U, a.coff, Tx);
+    // gx16[p][l*128 + o] = b_inx[l][o] + sum_c in_x[l].W[o][c] xm[p][c]
+    int rc = swn_bf16g_plain(wx16, g.L * 128, xm16, 0, (size_t)batch * Tx * A0x * 2, A0x, 1, (int)Tp, batch, packed + a.y.bxr,
+                             gx16, g.L * 128, nullptr, 0, st);
+    if (rc < 0) return rc;
+    hipLaunchKernelGGL(bf16_input_kernel, dim3((unsigned)((Tp + 255) / 256), batch), dim3(256), 0, st, a);
+    const int n_chunks = batch * (int)((Tp + 15) / 16);
+    const int grid = (n_chunks + 3) / 4 < 256 ? (n_chunks + 3) / 4 : 256;
+    for (int l = 0; l < g.L; ++l)
+        hipLaunchKernelGGL(bf16_layer_kernel<2>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
+    const int n_tiles = batch * (int)((Tp + TN - 1) / TN);
+    hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(n_tiles < 512 ? n_tiles : 512), dim3(256), 4 * 12 * 64 * 16, st, a, n_tiles);
+    return swn_launch_status("swn_forward_drop");
+}
+
 extern "C" size_t swn_bf16_weight_bytes(const swn_net_desc* d) {
     SwnGeom g;
     if (bf_geom(d, &g) < 0) return swn_bf16g_geom(d, &g) < 0 ? 0 : swn_bf16g_weight_bytes(g);
@@ -982,18 +1125,10 @@ extern "C" int swn_pack_bf16(const swn_net_desc* d, const float* packed, void* w
     if (rc < 0) return rc;
     if (!packed || !wbf_) return SWN_E_BADARG;
     SwnLayout y; swn_make_layout(&g, &y);
-    const BfOffsets o = bf_offsets(g);
     unsigned short* wbf = reinterpret_cast<unsigned short*>(wbf_);
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(pack_wd_kernel, dim3((g.L * 8 * 4 * 512 + 255) / 256), dim3(256), 0, st,
-                       packed + y.wd, g.L, wbf + o.wd);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3((8 * g.L * 2 * 512 + 255) / 256), dim3(256), 0, st,
-                       packed + y.wsk, g.L * 64, 128, g.L * 64, 8, g.L * 2, wbf + o.wsk);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3((8 * 4 * 512 + 255) / 256), dim3(256), 0, st,
-                       packed + y.w1, g.Sp, 128, 128, 8, 4, wbf + o.w1);
-    hipLaunchKernelGGL(pack_frag_kernel, dim3((4 * 512 + 255) / 256), dim3(256), 0, st,
-                       packed + y.w2, g.O1p, g.NO, 128, 1, 4, wbf + o.w2);
+    pack_bl6_images(g, y, packed, wbf, st);
     return swn_launch_status("swn_pack_bf16");
 }
 
@@ -1032,7 +1167,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
     a.hs = reinterpret_cast<unsigned short*>(work); a.out = out;
     a.B = batch; a.Tf = n_frames; a.Tp = (int)Tp; a.U = g.U; a.N = g.N; a.L = g.L; a.seg = g.seg; a.NO = g.NO;
     a.coff = g.seg;
-    a.off_wd = o.wd; a.off_wsk = o.wsk; a.off_w1 = o.w1; a.off_w2 = o.w2;
+    a.off_wd = o.wd; a.off_wsk = o.wsk; a.off_w1 = o.w1; a.off_w2 = o.w2; a.gx16 = nullptr;
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();
     hipLaunchKernelGGL(bf16_input_kernel, dim3((unsigned)((Tp + 255) / 256), batch), dim3(256), 0, st, a);
@@ -1073,7 +1208,7 @@ extern "C" int swn_forward_bf16(const swn_net_desc* d, const float* packed, cons
         }
     } else {
         for (int l = 0; l < g.L; ++l)
-            hipLaunchKernelGGL(bf16_layer_kernel<false>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
+            hipLaunchKernelGGL(bf16_layer_kernel<0>, dim3(grid), dim3(256), 0, st, a, l, g.dil[l], n_chunks);
     }
     const int hgrid = n_tiles < 512 ? n_tiles : 512;                            // two workgroups per CU
     hipLaunchKernelGGL(bf16_head_kernel<6>, dim3(hgrid), dim3(256), 4 * 12 * 64 * 16, st, a, n_tiles);

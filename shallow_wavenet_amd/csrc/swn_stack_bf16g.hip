@@ -29,7 +29,7 @@ __device__ __forceinline__ unsigned short f2bf(float x) { return __builtin_bit_c
 __device__ __forceinline__ float bf2f(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 __device__ __forceinline__ float sigm(float x) { return 1.f / (1.f + __expf(-x)); }
 
-enum { EPI_GATE = 0, EPI_RELU_BF16 = 1, EPI_F32 = 2 };
+enum { EPI_GATE = 0, EPI_RELU_BF16 = 1, EPI_F32 = 2, EPI_BF16 = 3 };   // EPI_BF16: bias (optional), no relu -> bf16 time-major
 
 struct GemmArgs {
     const unsigned short* A; int M, Kd;            // bf16 [M][Kd] row-major
@@ -207,10 +207,17 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
                     for (int r = 0; r < 4; ++r) hv[r] = f2bf(fmaxf(acc[i][j][r] + a.bias[m + r], 0.f));
                     uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
                     *reinterpret_cast<uint2*>(a.out_bf + ((size_t)b * a.Tp + t) * a.out_ld + m) = o;
+                } else if (EPI == EPI_BF16) {
+                    if (m >= a.M) continue;
+                    unsigned short hv[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) hv[r] = f2bf(acc[i][j][r] + (a.bias ? a.bias[m + r] : 0.f));
+                    uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
+                    *reinterpret_cast<uint2*>(a.out_bf + ((size_t)b * a.Tp + t) * a.out_ld + m) = o;
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r)
-                        if (m + r < a.NO) a.out_f[((size_t)b * a.NO + m + r) * a.Tp + t] = acc[i][j][r] + a.bias[m + r];
+                        if (m + r < a.NO) a.out_f[((size_t)b * a.NO + m + r) * a.Tp + t] = acc[i][j][r] + (a.bias ? a.bias[m + r] : 0.f);
                 }
             }
         }
@@ -321,6 +328,23 @@ void launch_gemm(GemmArgs a, int ntt, int nmt, int batch, hipStream_t st) {
 }
 
 }  // namespace
+
+// Plain GEMM over bf16 time-major rows on the tiled kernel of this file (the dropout-mode in_x products and their data
+// gradient, csrc/swn_stack_bf16.hip / swn_bwd_bl6.hip): for every position p = (b, t < Tp)
+//     out[p][m] = bias[m] + sum_{blk < nblk} sum_{i < KB} A[m][blk*KB + i] * src[blk*blk_stride + p*KB + i]
+// A: bf16 [M][nblk*KB] row-major (KB % 32 == 0; M % 4 == 0 for the bf16 output); bias may be null.  out_bf != null: bf16 rows of out_ld elements;
+// else out_f: fp32 channel-major (B, NO, Tp), rows m < NO.
+int swn_bf16g_plain(const unsigned short* A, int M, const unsigned short* src, size_t blk_stride, size_t src_bytes, int KB, int nblk,
+                    int Tp, int B, const float* bias, unsigned short* out_bf, int out_ld, float* out_f, int NO, hipStream_t st) {
+    if (KB % 32 != 0 || (out_bf && M % 4 != 0) || src_bytes >= (1ull << 31) || (size_t)M * nblk * KB * 2 >= (1ull << 31)) return SWN_E_UNSUPPORTED;
+    GemmArgs a = {};
+    a.A = A; a.M = M; a.Kd = nblk * KB; a.src = src; a.blk_stride = blk_stride; a.src_bytes = src_bytes; a.KB = KB; a.nblk = nblk;
+    a.shift0 = 0; a.shift_step = 0; a.Tp = Tp; a.B = B; a.bias = bias; a.out_bf = out_bf; a.out_ld = out_ld; a.out_f = out_f; a.NO = NO;
+    const int tx = (Tp + 127) / 128, nmt = (M + TM - 1) / TM;
+    if (out_bf) launch_gemm<EPI_BF16>(a, tx, nmt, B, st);
+    else launch_gemm<EPI_F32>(a, tx, nmt, B, st);
+    return SWN_OK;
+}
 
 // geometry class of this file: Laplace or softmax, H a multiple of 64 (row tiles of 64 channels, k-tiles of 32), S and O1
 // multiples of 32, at most 256 input-layer channels per block

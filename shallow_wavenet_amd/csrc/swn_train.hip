@@ -1515,9 +1515,11 @@ int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* pac
 // fused per-layer backward of the BL6 class in the mixed-precision mode (csrc/swn_bwd_bl6.hip)
 bool swn_bl6_bwd_supported(const SwnGeom& g, int B, long Tp, int n_frames);
 size_t swn_bl6_bwd_scratch_bytes(const SwnGeom& g, int B, long Tp);
+size_t swn_bl6_bwd_drop_scratch_bytes(const SwnGeom& g, int B, long Tp);
 int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
                       const void* hs_bf16, const float* grad_out, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
-                      long Tp, hipStream_t st);
+                      long Tp, hipStream_t st, const unsigned short* gx16 = nullptr, const unsigned short* xm16 = nullptr,
+                      float* dxm = nullptr);
 
 namespace {
 
@@ -1541,6 +1543,14 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     const long T = (long)n_frames * g.U;
     const int Tp = (int)(g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1);
     if (Tp < 1) return SWN_E_BADARG;
+    // dropout mode, BL6 class, mixed-precision mode: the forward of the same call mode was swn_bl6_drop_forward (same predicate),
+    // fwd_work holds its SwnBl6DropLayout and the layers take the fused backward with sample-rate in_x operands
+    const bool drop_fused = drop && !hs_opt && !hs_bf16 && mode_bf16() && swn_bl6_drop_supported(g, batch, Tp, n_frames, drop_h);
+    SwnBl6DropLayout dlo{};
+    if (drop_fused) {
+        dlo = swn_bl6_drop_layout(g, batch, Tp);
+        hs_bf16 = reinterpret_cast<const unsigned char*>(fwd_work) + dlo.hs16;
+    }
     {   // the contraction kernels address one utterance's operands with 32-bit byte offsets
         size_t widest = (size_t)(g.L + 1) * g.H;
         if ((size_t)g.S > widest) widest = g.S;
@@ -1579,10 +1589,12 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
                                ? gx + r64((size_t)B * L * H2 * Tp) : a_keep;   // a_keep: swn_forward_bf16_keep's buffer (same slots)
     float* dxm = dfe + r64(fe_tot * B * n_frames);
     float* hmask = dxm + r64((size_t)B * g.A0 * Tx);               // dropout mode only: masked input of a layer (B, H, Tp)
+    float* bl6_scratch = nullptr;
     if (hs_bf16) {                                     // compact layout: none of the fp32 sample-rate scratch exists
         dcond = work;
         dfe = dcond + r64((size_t)B * n_frames * g.N);
         dxm = dfe + r64(fe_tot * B * n_frames);
+        bl6_scratch = drop_fused ? dxm + r64((size_t)B * g.A0 * Tx) : dxm;      // dropout mode: d xm (B, A0, Tx) first
     }
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // teacher-forced chain without dropout: the partial g w_up copies of cond_bwd_kernel sit where the dropout mode keeps dxm
@@ -1649,9 +1661,13 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     ga.gwxa = g.audio_in ? gpacked + y.wxa : nullptr;
     // ---- layers, last to first
     if (hs_bf16) {
-        if (drop || !swn_bl6_bwd_supported(g, B, Tp, n_frames)) return SWN_E_UNSUPPORTED;
+        if ((drop && !drop_fused) || !swn_bl6_bwd_supported(g, B, Tp, n_frames)) return SWN_E_UNSUPPORTED;
+        const unsigned char* fw = reinterpret_cast<const unsigned char*>(fwd_work);
         const int rcl = swn_bl6_bwd_stack(g, y, packed, cond, reinterpret_cast<const float*>(audio), hs_bf16, grad_out, dcond, gpacked,
-                                          dxm, B, n_frames, Tp, st);
+                                          bl6_scratch, B, n_frames, Tp, st,
+                                          drop_fused ? reinterpret_cast<const unsigned short*>(fw + dlo.gx16) : nullptr,
+                                          drop_fused ? reinterpret_cast<const unsigned short*>(fw + dlo.xm16) : nullptr,
+                                          drop_fused ? dxm : nullptr);
         if (rcl < 0) return rcl;
     }
     for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
@@ -1822,7 +1838,14 @@ extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch
     if (!base) return 0;
     const long T = (long)n_frames * g.U;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
-    return base + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg))) + r64((size_t)batch * g.H * Tp);
+    const size_t chain = base + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg))) + r64((size_t)batch * g.H * Tp);
+    size_t fused = 0;                                  // the fused BL6 path: d cond (unused) | front-end gradients | d xm | its scratch
+    if (g.kind == SWN_KIND_LAPLACE && swn_bl6_bwd_supported(g, batch, Tp, n_frames)) {
+        size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
+        fused = r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) + r64((size_t)batch * g.A0 * (T - g.seg)) +
+                r64((swn_bl6_bwd_drop_scratch_bytes(g, batch, Tp) + 3) / 4);
+    }
+    return chain > fused ? chain : fused;
 }
 
 extern "C" int swn_backward_drop(const swn_net_desc* d, const float* packed, const float* aux, const float* fe_work,
