@@ -120,7 +120,8 @@ int    swn_unfold_grads_device(const swn_net_desc* d, const float* gpacked_dev, 
  * consumers as  in_x(x)[o,t] = bx[l][o] + sum_s w_up[(t+s)%U] * cond[b][(t+s)/U][l][s][o].
  *   aux_dev   (B, n_aux, Tf)             in
  *   work_dev  swn_frontend_work_floats() scratch
- *   cond_dev  (B, Tf, L*seg*2H)          out                                            */
+ *   cond_dev  (B, Tf, L*seg*2H)          out; NULL = stop after conv_aux (the dropout mode, swn_forward_drop, applies
+ *                                        in_x at sample rate and reads only the activations kept in work_dev) */
 size_t swn_frontend_work_floats(const swn_net_desc* d, int batch, int n_frames);
 size_t swn_cond_floats(const swn_net_desc* d, int batch, int n_frames);
 int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float* aux_dev,

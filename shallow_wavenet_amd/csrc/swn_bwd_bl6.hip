@@ -32,6 +32,7 @@
 // = 1.4 KB (the chain: ~5.7 KB, plus the skip path's data gradient as a separate 384 x 128 GEMM and a memset of the
 // carries); head 1.8 KB; weight-gradient jobs 512 B each.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_bf16.h>
 #include "swn_geom.hpp"
 
@@ -428,6 +429,9 @@ __global__ __launch_bounds__(BwShape<HALF>::THREADS, 1) void bl6_layer_bwd_kerne
             }
             // g w_up[jj] += sum_o2 dgx[o2][t] * cond[f][o2]: finish the sum over the four lane groups (and, through the LDS
             // accumulator, over the two waves of a frame)
+            // (without the LDS atomic below nothing separates two chunks for the scheduler: it then hoists the next chunk's loads
+            //  over this chunk's gates and the half-frame form spills 97 registers)
+            if (GX) __builtin_amdgcn_sched_barrier(0);
             if (!GX) {
                 pw += __shfl_xor(pw, 16);
                 pw += __shfl_xor(pw, 32);
@@ -839,10 +843,8 @@ int launch_layer_h(const BwArgs& a, int l, int dil, int dil_up, int n_units, int
 template <int MODE, bool GX = false>
 int launch_layer(const BwArgs& a, int l, int dil, int dil_up, int n_units, int Fu, hipStream_t st) {
     // (the last launch carries 64 more accumulators per lane for the input layer: always in halves, or it spills)
-    // (dropout mode: whole frames at every size - the half-frame form of the GX kernels spills, 97 registers at 168)
-    if constexpr (GX) return launch_layer_h<MODE, false, true>(a, l, dil, dil_up, n_units, Fu, st);
-    else return (MODE == 2 || n_units < 2 * 2048) ? launch_layer_h<MODE, true, false>(a, l, dil, dil_up, n_units, Fu, st)
-                                                  : launch_layer_h<MODE, false, false>(a, l, dil, dil_up, n_units, Fu, st);
+    return (MODE == 2 || n_units < 2 * 2048) ? launch_layer_h<MODE, true, GX>(a, l, dil, dil_up, n_units, Fu, st)
+                                             : launch_layer_h<MODE, false, GX>(a, l, dil, dil_up, n_units, Fu, st);
 }
 // fp32 [rows][ld] -> transposed bf16 [cols (padded to dcols rows... )]: dst[c][r] = src[r][c] for c < cols, zero rows c >= cols
 __global__ void rowsT_to_bf16_kernel(const float* __restrict__ src, int ld, int rows, int cols, int drows, unsigned short* __restrict__ dst) {
@@ -977,7 +979,8 @@ int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed,
                                         gpacked + y.wx + (size_t)l * 128 * g.A0p + 128 * cb, g.A0p, nullptr,
                                         g.A0 - 128 * cb < 128 ? g.A0 - 128 * cb : 128};
                     if (nj == WG_MAXJOBS || (l == g.L - 1 && cb == ncb - 1)) {
-                        hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split, nj), dim3(256), 0, st, wa, tiles_per_b, n_tiles);
+                        const int split2 = n_tiles < 48 ? n_tiles : 48;      // 2.71 / 2.63 / 2.63 / 2.84 ms per step at 96 / 48 / 32 / 160
+                        hipLaunchKernelGGL(bl6_wgrad_kernel, dim3(split2, nj), dim3(256), 0, st, wa, tiles_per_b, n_tiles);
                         nj = 0;
                     }
                 }

@@ -245,7 +245,7 @@ extern "C" int swn_frontend(const swn_net_desc* d, const float* packed, const fl
                             int batch, int n_frames, float* work, float* cond, void* stream_) {
     SwnGeom g; int rc = swn_make_geom(d, &g);
     if (rc < 0) return rc;
-    if (!packed || !aux || !work || !cond || batch < 1 || n_frames < 1 || batch > 65535) return SWN_E_BADARG;
+    if (!packed || !aux || !work || batch < 1 || n_frames < 1 || batch > 65535) return SWN_E_BADARG;
     SwnLayout y; swn_make_layout(&g, &y);
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls; only our launches are reported
@@ -280,7 +280,7 @@ extern "C" int swn_frontend(const swn_net_desc* d, const float* packed, const fl
         src = cur;
         cur += bt * g.aux_cout[i];
     }
-    {
+    if (cond) {                            // null: the caller only wants the conv_aux activations (dropout mode)
         dim3 grid((n_frames + 63) / 64, (g.N + 63) / 64, batch);
         hipLaunchKernelGGL(cond_gemm_kernel, grid, dim3(256), 0, st, src, packed + y.wx, cond,
                            n_frames, g.N, g.A0, g.A0p);

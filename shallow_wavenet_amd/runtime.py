@@ -309,10 +309,16 @@ class HipNet:
     def _forward_train_drop(self, aux, audio, drop):
         cfg = self.cfg
         aux = aux.to(self.device, torch.float32).contiguous()
-        self.frontend(aux)
-        fe_work = self._last_frontend_work
         soft = cfg.kind == "softmax"
         B, Tf = aux.shape[0], aux.shape[2]
+        d = ctypes.byref(self.desc)
+        if aux.shape[1] != cfg.n_aux:
+            raise RuntimeError(f"aux has {aux.shape[1]} channels, model expects {cfg.n_aux}")
+        # conv_aux activations only: aux_drop acts at sample rate, the hoisted in_x products (cond) are not used
+        fe_work = torch.empty(self.lib.swn_frontend_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
+        with _ops._on(self.device):
+            _lib.check(self.lib.swn_frontend(d, _ptr(self.packed), _ptr(aux), B, Tf, _ptr(fe_work), _ptr(None),
+                                             _stream_ptr(self.device)), "frontend")
         T = Tf * cfg.U
         Tp = T - 1 if soft else T - 2 * cfg.seg + 1
         coff = 1 if soft else cfg.seg
@@ -320,7 +326,6 @@ class HipNet:
         drop_x, drop_h, ptrs = self._drop_args(drop)
         if tuple(drop_x.shape) != (B, cfg.A0, T - coff) or any(m is not None and tuple(m.shape) != (B, cfg.H, Tp) for m in drop_h):
             raise ValueError("dropout mask shapes must be (B, A0, T-coff) and (B, H, Tp)")
-        d = ctypes.byref(self.desc)
         work = torch.empty(self.lib.swn_forward_drop_work_floats(d, B, Tf), dtype=torch.float32, device=self.device)
         out = torch.empty((B, cfg.n_out, Tp), dtype=torch.float32, device=self.device)
         mode = current_precision()
