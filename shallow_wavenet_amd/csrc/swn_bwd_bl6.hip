@@ -884,11 +884,11 @@ int swn_bf16g_plain(const unsigned short* A, int M, const unsigned short* src, s
 // The whole stack backward behind d raw: head (out_2, out_1, skip), the gated layers, the input layer.  Fills dcond and every
 // sample-rate section of gpacked (zeroed by the caller): w2 b2 w1 b1 wsk bsk wd bd bx wup cb cv cc.
 // Dropout mode (gx16 != null: the forward was swn_bl6_drop_forward; cond and dcond are not used, scratch holds
-// swn_bl6_bwd_drop_scratch_bytes): fills wx and bxr instead of bx / wup, and dxm (B, A0, Tx) fp32 = in_x^T d gx, the
+// swn_bl6_bwd_drop_scratch_bytes): fills wx and bxr instead of bx / wup, and dxm16 [B][Tx][A0x] bf16 = in_x^T d gx, the
 // gradient wrt the masked conditioning (the caller's xm backward turns it into d C, g w_up, g b_up).
 int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
                       const void* hs_bf16, const float* grad_out, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
-                      long Tp, hipStream_t st, const unsigned short* gx16, const unsigned short* xm16, float* dxm) {
+                      long Tp, hipStream_t st, const unsigned short* gx16, const unsigned short* xm16, unsigned short* dxm16) {
     BwArgs a;
     a.P = packed; a.y = y; a.cond = cond; a.audio = audio; a.hs = reinterpret_cast<const unsigned short*>(hs_bf16);
     unsigned char* p = reinterpret_cast<unsigned char*>(scratch);
@@ -987,13 +987,14 @@ int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed,
         }
     }
     if (gx16) {
-        // dxm[b][c][u] = sum_{l,o} in_x[l].W[o][c] d gx_l[b][u][o]: A = the transposed matrices [c][l*128 + o], k = L blocks of 128
+        // dxm16[b][u][c] = sum_{l,o} in_x[l].W[o][c] d gx_l[b][u][o]: A = the transposed matrices [c][l*128 + o] (zero rows
+        // A0..A0x), k = L blocks of 128
         const int A0x = swn_a0x(&g);
         hipLaunchKernelGGL(rowsT_to_bf16_kernel, dim3((unsigned)(((size_t)A0x * g.L * 128 + 255) / 256)), dim3(256), 0, st,
                            packed + y.wx, g.A0p, g.L * 128, g.A0, A0x, wxt);
         const size_t lstride2 = (size_t)B * Tp * 128;
-        const int rcg = swn_bf16g_plain(wxt, g.A0, a.dgx16, lstride2, (size_t)g.L * lstride2 * 2, 128, g.L, (int)Tp, B, nullptr,
-                                        nullptr, 0, dxm, g.A0, st);
+        const int rcg = swn_bf16g_plain(wxt, A0x, a.dgx16, lstride2, (size_t)g.L * lstride2 * 2, 128, g.L, (int)Tp, B, nullptr,
+                                        dxm16, A0x, nullptr, 0, st);
         if (rcg < 0) return rcg;
     }
     return swn_launch_status("swn_backward_bf16");

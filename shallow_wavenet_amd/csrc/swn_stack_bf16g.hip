@@ -70,6 +70,10 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
     const int t0 = (gt - b * a.ntt) * TNW, m0 = by * TM;
     // tile row -> matrix row
     auto rowmap = [&](int tr) -> int {
+        // bf16 time-major outputs: tile row 16 i + 4 g + r of a wave's 64 holds matrix row 16 g + 4 i + r, so that the 16 values a
+        // lane finishes for its position are 16 consecutive outputs (two 16-byte stores; the four lane groups complete a
+        // 128-byte row segment - in tile order they were 8-byte stores, 32 contiguous bytes per position)
+        if (EPI == EPI_RELU_BF16 || EPI == EPI_BF16) return m0 + (tr & ~63) + 16 * ((tr >> 2) & 3) + 4 * ((tr >> 4) & 3) + (tr & 3);
         if (EPI != EPI_GATE) return m0 + tr;
         const int c0 = by * 64, wmr = tr >> 6, mt = (tr & 63) >> 4, r = tr & 15;
         const int ch = c0 + 32 * wmr + 16 * (mt >> 1) + r;
@@ -197,28 +201,38 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
         for (int j = 0; j < WNT; ++j) {
             const int t = t0 + 16 * WNT * wn + 16 * j + n;
             if (t >= a.Tp) continue;
+            if (EPI == EPI_RELU_BF16 || EPI == EPI_BF16) {
+                const int mb = m0 + 64 * wm + 16 * g4;                       // 16 consecutive outputs of this lane (rowmap)
+                unsigned short* orow = a.out_bf + ((size_t)b * a.Tp + t) * a.out_ld + mb;
+#pragma unroll
+                for (int ip = 0; ip < 2; ++ip) {
+                    unsigned wv[4];
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int i = 2 * ip + q, m = mb + 4 * i;
+                        float v[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            v[r] = acc[i][j][r] + ((a.bias && m + r < a.M) ? a.bias[m + r] : 0.f);
+                            if (EPI == EPI_RELU_BF16) v[r] = fmaxf(v[r], 0.f);
+                        }
+                        wv[2 * q] = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16); wv[2 * q + 1] = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
+                    }
+                    const int m = mb + 8 * ip;                                // M % 4 == 0
+                    if (m + 8 <= a.M && (a.out_ld & 7) == 0) *reinterpret_cast<uint4*>(orow + 8 * ip) = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                    else {
+                        if (m < a.M) *reinterpret_cast<uint2*>(orow + 8 * ip) = make_uint2(wv[0], wv[1]);
+                        if (m + 4 < a.M) *reinterpret_cast<uint2*>(orow + 8 * ip + 4) = make_uint2(wv[2], wv[3]);
+                    }
+                }
+                continue;
+            }
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int m = m0 + 64 * wm + 16 * i + 4 * g4;
-                if (EPI == EPI_RELU_BF16) {
-                    if (m >= a.M) continue;                   // M is a multiple of 4 here
-                    unsigned short hv[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[r] = f2bf(fmaxf(acc[i][j][r] + a.bias[m + r], 0.f));
-                    uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
-                    *reinterpret_cast<uint2*>(a.out_bf + ((size_t)b * a.Tp + t) * a.out_ld + m) = o;
-                } else if (EPI == EPI_BF16) {
-                    if (m >= a.M) continue;
-                    unsigned short hv[4];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) hv[r] = f2bf(acc[i][j][r] + (a.bias ? a.bias[m + r] : 0.f));
-                    uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
-                    *reinterpret_cast<uint2*>(a.out_bf + ((size_t)b * a.Tp + t) * a.out_ld + m) = o;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (m + r < a.NO) a.out_f[((size_t)b * a.NO + m + r) * a.Tp + t] = acc[i][j][r] + (a.bias ? a.bias[m + r] : 0.f);
-                }
+                for (int r = 0; r < 4; ++r)
+                    if (m + r < a.NO) a.out_f[((size_t)b * a.NO + m + r) * a.Tp + t] = acc[i][j][r] + (a.bias ? a.bias[m + r] : 0.f);
             }
         }
     }

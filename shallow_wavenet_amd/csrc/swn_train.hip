@@ -1409,6 +1409,79 @@ __global__ __launch_bounds__(256) void xm_bwd_kernel(const float* __restrict__ d
     if (lane == 0 && gb != 0.f) atomicAdd(gbup, gb);
 }
 
+// The same backward with d xm as bf16 TIME-MAJOR rows [b][u][A0x] (the fused BL6 dropout path: what its in_x data-gradient
+// GEMM stores, csrc/swn_bwd_bl6.hip).  Workgroup = (FR frames, 64 channels, utterance); a frame's U x 64 tile is staged in LDS
+// (pitch 33 dwords: the lanes of a wave then read one channel of 64 positions without bank conflicts), the mask is read
+// along its contiguous axis as above.
+constexpr int XM16_CC = 64;
+__global__ __launch_bounds__(256) void xm_bwd16_kernel(const unsigned short* __restrict__ dxm16, const float* __restrict__ drop_x,
+                                                       const float* __restrict__ C, const float* __restrict__ P, size_t wup,
+                                                       float* __restrict__ dC, float* __restrict__ gwup, float* __restrict__ gbup,
+                                                       int A0, int A0x, int Tf, int U, int coff, int Tx, int FR) {
+    __shared__ unsigned tile[256 * 33];                          // U <= 256 positions x 32 dwords (64 bf16) + 1 pad
+    __shared__ float red[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, b = blockIdx.z;
+    const int c0 = blockIdx.y * XM16_CC;
+    float wu[4], gw[4] = {0.f, 0.f, 0.f, 0.f}, gb = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) wu[q] = lane + 64 * q < U ? P[wup + lane + 64 * q] : 0.f;
+    const __amdgpu_buffer_rsrc_t rM = rsrc_of(drop_x + (size_t)b * A0 * Tx);
+    const int f1 = (blockIdx.x + 1) * FR < Tf ? (blockIdx.x + 1) * FR : Tf;
+    const int nq = (U + 63) / 64;
+    for (int f = blockIdx.x * FR; f < f1; ++f) {
+        __syncthreads();                                         // the previous frame's tile has been read
+        for (int e = tid; e < U * 8; e += 256) {                 // (position, 16-byte chunk of its 128-byte segment)
+            const int j = e >> 3, ch = e & 7, u = f * U + j - coff;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (u >= 0 && u < Tx && c0 + 8 * ch < A0x) v = *reinterpret_cast<const uint4*>(dxm16 + ((size_t)b * Tx + u) * A0x + c0 + 8 * ch);
+            unsigned* d = tile + j * 33 + 4 * ch;
+            d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+        }
+        __syncthreads();
+        unsigned off[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int j = lane + 64 * q, u = f * U + j - coff;
+            off[q] = (j < U && u >= 0 && u < Tx) ? (unsigned)(u * 4) : SWN_OOB;
+        }
+        for (int ci = w; ci < XM16_CC; ci += 8) {                // two channels per pass
+            float m[2][4], cv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int c = c0 + ci + 4 * h;
+                const unsigned ro = c < A0 ? (unsigned)((size_t)c * Tx * 4) : SWN_OOB;
+                cv[h] = c < A0 ? C[((size_t)b * A0 + c) * Tf + f] : 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[h][q] = q < nq ? bld1(rM, ((off[q] | ro) & SWN_OOB) ? SWN_OOB : off[q] + ro) : 0.f;
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int cl = ci + 4 * h, c = c0 + cl;
+                float part = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (q >= nq) break;
+                    const int j = lane + 64 * q;
+                    const unsigned wd = j < U ? tile[j * 33 + (cl >> 1)] : 0u;
+                    const float x = __builtin_bit_cast(float, (cl & 1) ? (wd & 0xffff0000u) : (wd << 16));
+                    const float dx = x * m[h][q];
+                    gw[q] = fmaf(dx, cv[h], gw[q]); part = fmaf(dx, wu[q], part); gb += dx;
+                }
+#pragma unroll
+                for (int sft = 32; sft > 0; sft >>= 1) part += __shfl_xor(part, sft);
+                if (lane == 0 && c < A0) dC[((size_t)b * A0 + c) * Tf + f] = part;
+            }
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) red[w][lane + 64 * q] = gw[q];
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) gb += __shfl_xor(gb, sft);
+    __syncthreads();
+    if (tid < U) atomicAdd(gwup + tid, red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid]);
+    if (lane == 0 && gb != 0.f) atomicAdd(gbup, gb);
+}
+
 }  // namespace
 
 // relu(skip) and relu(out_1) from fp32 hidden states already in `work` (layout of swn_forward_work_floats) through the
@@ -1519,7 +1592,7 @@ size_t swn_bl6_bwd_drop_scratch_bytes(const SwnGeom& g, int B, long Tp);
 int swn_bl6_bwd_stack(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* cond, const float* audio,
                       const void* hs_bf16, const float* grad_out, float* dcond, float* gpacked, void* scratch, int B, int n_frames,
                       long Tp, hipStream_t st, const unsigned short* gx16 = nullptr, const unsigned short* xm16 = nullptr,
-                      float* dxm = nullptr);
+                      unsigned short* dxm16 = nullptr);
 
 namespace {
 
@@ -1594,7 +1667,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         dcond = work;
         dfe = dcond + r64((size_t)B * n_frames * g.N);
         dxm = dfe + r64(fe_tot * B * n_frames);
-        bl6_scratch = drop_fused ? dxm + r64((size_t)B * g.A0 * Tx) : dxm;      // dropout mode: d xm (B, A0, Tx) first
+        bl6_scratch = drop_fused ? dxm + r64((size_t)B * Tx * swn_a0x(&g) / 2) : dxm;      // dropout mode: d xm first, bf16 [B][Tx][A0x]
     }
     if (hipMemsetAsync(gpacked, 0, y.total * sizeof(float), st) != hipSuccess) return SWN_E_LAUNCH;
     // teacher-forced chain without dropout: the partial g w_up copies of cond_bwd_kernel sit where the dropout mode keeps dxm
@@ -1667,7 +1740,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
                                           bl6_scratch, B, n_frames, Tp, st,
                                           drop_fused ? reinterpret_cast<const unsigned short*>(fw + dlo.gx16) : nullptr,
                                           drop_fused ? reinterpret_cast<const unsigned short*>(fw + dlo.xm16) : nullptr,
-                                          drop_fused ? dxm : nullptr);
+                                          drop_fused ? reinterpret_cast<unsigned short*>(dxm) : nullptr);
         if (rcl < 0) return rcl;
     }
     for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
@@ -1753,7 +1826,13 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         chn[0] = g.n_aux; act[0] = p; dact[0] = q; p += bt * g.n_aux; q += bt * g.n_aux;
         for (int i = 0; i < g.auxl; ++i) { chn[i + 1] = g.aux_cout[i]; act[i + 1] = p; dact[i + 1] = q; p += bt * g.aux_cout[i]; q += bt * g.aux_cout[i]; }
         const float* C = act[g.auxl];
-        if (drop) {
+        if (drop_fused) {
+            const int cb = (g.A0 + XM16_CC - 1) / XM16_CC;
+            int FRx = (int)(((long)cb * n_frames * B) / 1024); FRx = FRx < 1 ? 1 : (FRx > 16 ? 16 : FRx);
+            hipLaunchKernelGGL(xm_bwd16_kernel, dim3((n_frames + FRx - 1) / FRx, cb, B), dim3(256), 0, st,
+                               reinterpret_cast<const unsigned short*>(dxm), drop_x, C, packed, y.wup, dact[g.auxl], gpacked + y.wup,
+                               gpacked + y.bup, g.A0, swn_a0x(&g), n_frames, g.U, coff, Tx, FRx);
+        } else if (drop) {
             const int cb = (g.A0 + XM_CC - 1) / XM_CC;
             int FRx = (int)(((long)cb * n_frames * B) / 1024); FRx = FRx < 1 ? 1 : (FRx > 16 ? 16 : FRx);
             hipLaunchKernelGGL(xm_bwd_kernel, dim3((n_frames + FRx - 1) / FRx, cb, B), dim3(256), 0, st, dxm, drop_x, C, packed, y.wup,
@@ -1842,7 +1921,7 @@ extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch
     size_t fused = 0;                                  // the fused BL6 path: d cond (unused) | front-end gradients | d xm | its scratch
     if (g.kind == SWN_KIND_LAPLACE && swn_bl6_bwd_supported(g, batch, Tp, n_frames)) {
         size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
-        fused = r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) + r64((size_t)batch * g.A0 * (T - g.seg)) +
+        fused = r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) + r64((size_t)batch * swn_a0x(&g) * (T - g.seg) / 2) +
                 r64((swn_bl6_bwd_drop_scratch_bytes(g, batch, Tp) + 3) / 4);
     }
     return chain > fused ? chain : fused;
