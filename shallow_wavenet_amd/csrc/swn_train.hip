@@ -1444,19 +1444,21 @@ __global__ __launch_bounds__(256) void xm_bwd16_kernel(const unsigned short* __r
             const int j = lane + 64 * q, u = f * U + j - coff;
             off[q] = (j < U && u >= 0 && u < Tx) ? (unsigned)(u * 4) : SWN_OOB;
         }
-        for (int ci = w; ci < XM16_CC; ci += 8) {                // two channels per pass
-            float m[2][4], cv[2];
+        // a wave's 16 channels (w, w + 4, ...) in two passes of eight: all mask loads of a pass in flight together (two per
+        // pass, as in the fp32 form, left a frame eight dependent round trips long)
+        for (int half = 0; half < 2; ++half) {
+            float m[8][4], cv[8];
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int c = c0 + ci + 4 * h;
+            for (int h = 0; h < 8; ++h) {
+                const int c = c0 + w + 4 * (8 * half + h);
                 const unsigned ro = c < A0 ? (unsigned)((size_t)c * Tx * 4) : SWN_OOB;
                 cv[h] = c < A0 ? C[((size_t)b * A0 + c) * Tf + f] : 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) m[h][q] = q < nq ? bld1(rM, ((off[q] | ro) & SWN_OOB) ? SWN_OOB : off[q] + ro) : 0.f;
             }
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int cl = ci + 4 * h, c = c0 + cl;
+            for (int h = 0; h < 8; ++h) {
+                const int cl = w + 4 * (8 * half + h), c = c0 + cl;
                 float part = 0.f;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
