@@ -901,6 +901,7 @@ struct GateBwd {
     SwnGeom g; SwnLayout y;
     const float* P; const float* cond; const void* audio;
     const float* hs; float* dhs; float* a_da; float* dgx;
+    long dgx_sb;           // elements between two utterances' (2H, Tp) blocks of dgx
     int B, Tf, Tp, coff, l;
     // dropout mode (appended, null = off)
     const float* gx;       // (B, L, 2H, Tp) sample-rate in_x products (no bias) of the masked conditioning
@@ -970,8 +971,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
         rz[0] = (unsigned short)(pk & 0xffffu); rz[a.da16_odd + 1] = (unsigned short)(pk & 0xffffu);
         rc[0] = (unsigned short)(pk >> 16); rc[a.da16_odd + 1] = (unsigned short)(pk >> 16);
     }
-    a.dgx[((size_t)b * H2 + o) * a.Tp + t] = dz * sz;
-    a.dgx[((size_t)b * H2 + H + o) * a.Tp + t] = dc * sc;
+    a.dgx[(size_t)b * a.dgx_sb + (size_t)o * a.Tp + t] = dz * sz;
+    a.dgx[(size_t)b * a.dgx_sb + (size_t)(H + o) * a.Tp + t] = dc * sc;
     if (KIND == SWN_KIND_SOFTMAX && g.audio_in && a.gwxa) {      // one-hot input column idx: d in_x.W[o][A0+idx] += dgx
         atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + o, dz * sz);
         atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + H + o, dc * sc);
@@ -1021,7 +1022,7 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
     const int ncol = U + seg - 1;
     wus[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
-    const __amdgpu_buffer_rsrc_t rD = rsrc_of(a.dgx + (size_t)b * H2 * a.Tp);
+    const __amdgpu_buffer_rsrc_t rD = rsrc_of(a.dgx + (size_t)b * a.dgx_sb);
     const int o2 = blockIdx.x * 64 + tid;
     float bsum = 0.f, wacc[2] = {0.f, 0.f};      // tid < 64: row sum ; tid >= 64: taps tid - 64 and tid + 128
     const int f1 = (blockIdx.y + 1) * FR < a.Tf ? (blockIdx.y + 1) * FR : a.Tf;
@@ -1316,11 +1317,17 @@ void launch_reduce(ReduceGemm g, int B, hipStream_t st) {
 int  swn_call_mode() { return t_call_mode; }
 void swn_call_mode_set(int mode) { t_call_mode = mode; }
 
+static size_t chain_floats(const SwnGeom& g, int batch, int n_frames);
 extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int n_frames) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0 || batch < 1 || n_frames < 1) return 0;
     const long T = (long)n_frames * g.U;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     if (Tp < 1) return 0;
+    return chain_floats(g, batch, n_frames);
+}
+static size_t chain_floats(const SwnGeom& g, int batch, int n_frames) {
+    const long T = (long)n_frames * g.U;
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
     return r64((size_t)batch * g.O1 * Tp) + r64((size_t)batch * g.S * Tp) + r64((size_t)batch * (g.L + 1) * g.H * Tp) +
            2 * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * n_frames * g.N) + r64(fw * batch * n_frames) +
@@ -1328,6 +1335,12 @@ extern "C" size_t swn_backward_work_floats(const swn_net_desc* d, int batch, int
            r64((size_t)batch * 2 * g.H * ((Tp + 2 + 31) & ~31L)) +     // two bf16 copies of a layer's da (mixed-precision GEMM operands)
            r64((size_t)g.L * g.K * g.H * 2 * g.H / 2) +               // transposed bf16 copy of the layer matrices (data gradients)
            r64((size_t)batch * g.H * ((Tp + 2 + 31) & ~31L));          // two bf16 copies of a layer's input (weight gradients' Q operand)
+}
+// floats of the dropout chain's scratch (swn_backward_drop without the kept d gx): the chain's + d xm + one masked layer input
+static size_t drop_chain_floats(const SwnGeom& g, int batch, int n_frames) {
+    const long T = (long)n_frames * g.U;
+    const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
+    return chain_floats(g, batch, n_frames) + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg))) + r64((size_t)batch * g.H * Tp);
 }
 
 namespace {
@@ -1730,7 +1743,11 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         launch_reduce(r, B, st);
     }
     }
-    ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx;
+    ga.P = packed; ga.cond = cond; ga.audio = audio; ga.hs = hs; ga.dhs = dhs; ga.a_da = a_da; ga.dgx = dgx; ga.dgx_sb = (long)H2 * Tp;
+    // dropout chain, seg == 1: every layer's d gx is kept - (B, L, 2H, Tp) at the end of the work buffer - so that the gradient wrt
+    // the masked conditioning is ONE contraction over the L * 2H rows of in_x behind the loop instead of L read-modify-write
+    // passes over d xm (257 MB each way at the run.sh geometry)
+    float* dgx_all = (drop && !drop_fused && g.seg == 1) ? work + drop_chain_floats(g, B, n_frames) : nullptr;
     ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
     ga.gx = drop ? gx : nullptr;
     ga.gwxa = g.audio_in ? gpacked + y.wxa : nullptr;
@@ -1747,6 +1764,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     }
     for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
         ga.l = l;
+        if (dgx_all) { dgx = dgx_all + (size_t)l * H2 * Tp; ga.dgx = dgx; ga.dgx_sb = (long)L * H2 * Tp; }
         // dropout mode: this layer's input is h_{l-1} times the mask drawn for layer l-1's output (cswnv_shift1.py:269-273)
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;
         ga.in_mul = in_mul;
@@ -1799,19 +1817,25 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
             {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
-                ReduceGemm r = {dgx, (long)H2 * Tp, Tp, 1, xm, (long)swn_a0x(&g) * Tx, Tx, 1,
+                ReduceGemm r = {dgx, ga.dgx_sb, Tp, 1, xm, (long)swn_a0x(&g) * Tx, Tx, 1,
                                 gpacked + y.wx + (size_t)l * g.seg * H2 * g.A0p, g.A0p, (long)H2 * g.A0p, 1,
                                 gpacked + y.bxr + (size_t)l * H2, H2, g.seg, g.A0, Tp, 1, 0, 1, 0};
                 r.QT = Tx;
                 launch_reduce(r, B, st);
             }
-            {   // dxm[c][u] (+)= sum_{s,o} W[l][o][c*seg+s] dgx[o][u-s]
+            if (!dgx_all) {   // dxm[c][u] (+)= sum_{s,o} W[l][o][c*seg+s] dgx[o][u-s]
                 TimeGemm t = {Wx, 1, (long)H2 * g.A0p, g.A0p, dgx, (long)H2 * Tp, Tp, 1, dxm, (long)g.A0 * Tx, Tx, nullptr, 0, 0,
                               g.A0, g.seg, H2, Tx, -1, 0, 1, l == L - 1 ? 0 : 1};
                 t.XT = Tp;
                 launch_time(t, B, st);
             }
         }
+    }
+    if (dgx_all) {   // dxm[c][u] = sum_{l,o} in_x[l].W[o][c] dgx_l[o][u]: rows n = l*2H + o of the [N][A0p] matrix are the k axis
+        TimeGemm t = {packed + y.wx, 1, 0, g.A0p, dgx_all, (long)L * H2 * Tp, Tp, 1, dxm, (long)g.A0 * Tx, Tx, nullptr, 0, 0,
+                      g.A0, 1, L * H2, Tx, -1, 0, 1, 0};
+        t.XT = Tp;
+        launch_time(t, B, st);
     }
     if (wup_part) hipLaunchKernelGGL(wup_fold_kernel, dim3(1), dim3(256), 0, st, wup_part, gpacked + y.wup, g.U);
     // ---- input layer (the fused layer path has done it from its accumulators)
@@ -1915,11 +1939,11 @@ extern "C" int swn_backward_keep(const swn_net_desc* d, const float* packed, con
 
 extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch, int n_frames) {
     SwnGeom g; if (swn_make_geom(d, &g) < 0) return 0;
-    const size_t base = swn_backward_work_floats(d, batch, n_frames);
-    if (!base) return 0;
+    if (!swn_backward_work_floats(d, batch, n_frames)) return 0;
     const long T = (long)n_frames * g.U;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
-    const size_t chain = base + r64((size_t)batch * g.A0 * (T - (g.kind == SWN_KIND_SOFTMAX ? 1 : g.seg))) + r64((size_t)batch * g.H * Tp);
+    // the generic chain's layout, + (seg == 1) every layer's d gx behind it
+    const size_t chain = drop_chain_floats(g, batch, n_frames) + (g.seg == 1 ? r64((size_t)batch * g.L * 2 * g.H * Tp) : 0);
     size_t fused = 0;                                  // the fused BL6 path: d cond (unused) | front-end gradients | d xm | its scratch
     if (g.kind == SWN_KIND_LAPLACE && swn_bl6_bwd_supported(g, batch, Tp, n_frames)) {
         size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
