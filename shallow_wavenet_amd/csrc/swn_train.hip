@@ -1816,7 +1816,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             else hipLaunchKernelGGL(cond_bwd_kernel<5>, cgrid, dim3(256), clds, st, ga, dcond, gpacked + y.bx, wup_part, FR);
         } else {
             const float* Wx = packed + y.wx + (size_t)l * g.seg * H2 * g.A0p;          // [s][o][c]
-            {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
+            if (!dgx_all) {   // g in_x.W[l][o][c*seg+s] += sum dgx[o][t] xm[c][t+s] ; g b_inx += rowsum(dgx)
                 ReduceGemm r = {dgx, ga.dgx_sb, Tp, 1, xm, (long)swn_a0x(&g) * Tx, Tx, 1,
                                 gpacked + y.wx + (size_t)l * g.seg * H2 * g.A0p, g.A0p, (long)H2 * g.A0p, 1,
                                 gpacked + y.bxr + (size_t)l * H2, H2, g.seg, g.A0, Tp, 1, 0, 1, 0};
@@ -1831,7 +1831,13 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
             }
         }
     }
-    if (dgx_all) {   // dxm[c][u] = sum_{l,o} in_x[l].W[o][c] dgx_l[o][u]: rows n = l*2H + o of the [N][A0p] matrix are the k axis
+    if (dgx_all) {   // the two in_x contractions over all layers at once (seg == 1: row n = l*2H + o of the [N][A0p] matrix)
+        // g in_x.W[n][c] += sum dgx[n][t] xm[c][t] ; g b_inx[n] += rowsum(dgx[n])
+        ReduceGemm r = {dgx_all, (long)L * H2 * Tp, Tp, 1, xm, (long)swn_a0x(&g) * Tx, Tx, 1, gpacked + y.wx, g.A0p, 0, 1,
+                        gpacked + y.bxr, L * H2, 1, g.A0, Tp, 1, 0, 1, 0};
+        r.QT = Tx;
+        launch_reduce(r, B, st);
+        // dxm[c][u] = sum_n in_x.W[n][c] dgx[n][u]
         TimeGemm t = {packed + y.wx, 1, 0, g.A0p, dgx_all, (long)L * H2 * Tp, Tp, 1, dxm, (long)g.A0 * Tx, Tx, nullptr, 0, 0,
                       g.A0, 1, L * H2, Tx, -1, 0, 1, 0};
         t.XT = Tp;
