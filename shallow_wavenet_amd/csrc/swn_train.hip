@@ -1587,6 +1587,14 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
                           int B, int Tx, int Tp, hipStream_t st) {
     const int H2 = 2 * g.H;
+    if (g.seg == 1) {                 // one launch over the L * 2H rows of the [N][A0p] matrix (row n = l*2H + o): gx is (B, L*2H, Tp)
+        const int A0x = swn_a0x(&g);
+        TimeGemm t = {packed + y.wx, g.A0p, 0, 1, xm, (long)A0x * Tx, Tx, 1, gx, (long)g.L * H2 * Tp, Tp, nullptr, 0, 0,
+                      g.L * H2, 1, A0x, Tp, 1, 0, 1, 0};
+        t.XT = Tx;
+        launch_time(t, B, st);
+        return SWN_OK;
+    }
     for (int l = 0; l < g.L; ++l) {   // gx[b][l][o][t] = sum_{s,c} W[l][o][c*seg+s] xm[b][c][t+s]
         // k runs over the A0x = 32-aligned rows of xm: beyond A0 the activations are zero rows and the weights whatever
         // follows in the packed buffer (padding, then the next row: finite), so the products vanish
