@@ -354,6 +354,14 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
            "includes": "forward + LaplaceLoss + backward + Adam step + parameter re-pack, wall clock"}
     peak = MFMA_BF16_TFLOPS if mode == "bf16" else MFMA_FP32_TFLOPS
     leg["roofline"] = _mfma(flops, ms, peak, kernel=kernel, algorithmic_flops="3 x forward (2 x MAC)")
+    if mode == "bf16" and cfg.H == 64 and cfg.K == 2 and cfg.seg == 1 and do_prob > 0:
+        # fused dropout path: the plain step's streams with the hoisted conditioning replaced by sample-rate rows -
+        # per position: mask 2 x 4 A0 (forward, backward) + xm16 3 x 2 A0x (written, read by two contractions) + gx16 L x 256 x 3
+        # (written, read by the forward and the backward layer kernels) + d gx16 L x 256 x 3 (written, read by two contractions)
+        # + d xm16 2 x 2 A0x, on top of the plain step's bytes below
+        a0x = (cfg.A0 + 31) // 32 * 32
+        bpp = (128 + 6 * 256 + 776 + 1800 + 6 * 1408 + 520 + 10 * 512) + 8 * cfg.A0 + 10 * a0x + 6 * cfg.L * 256
+        leg["roofline_hbm"] = _hbm(float(bpp) * pos, ms, kernel="fused dropout step, all sample-rate launches", algorithmic_bytes_per_position=bpp)
     if mode == "bf16" and cfg.H == 64 and cfg.K == 2 and cfg.seg == 1 and do_prob == 0:
         # the fused BL6 path is bound by its streams, not by the matrix cores: bytes per position of the
         # sample-rate launches - forward 128 + 6 x 256 + 776, head backward 1 800, six layer launches x 1 408, the last
@@ -474,8 +482,9 @@ def run_legs(dev, quick: bool = False):
     add("cfg4_ref6_step_bf16_dropout", train_leg, "cfg4 training step as run.sh trains: REF6, 8 x 16 500, do_prob 0.5 (masks drawn on the "
         "device), mixed precision", ref6, dev, 8, 150, "bf16", 3,
         "time_gemm_bf16t (forward layers, in_x at sample rate) + gate_fwd / gate_bwd + reduce_gemm_bf16s", do_prob=0.5)
-    add("cfg4_bl6_step_bf16_dropout", train_leg, "the same at BL6", bl6, dev, 8, 150, "bf16", 3,
-        "time_gemm_bf16t + gate_fwd / gate_bwd + reduce_gemm_bf16s (generic chain: the fused backward has no dropout form)", do_prob=0.5)
+    add("cfg4_bl6_step_bf16_dropout", train_leg, "the same at BL6", bl6, dev, 8, 150, "bf16", 5,
+        "xm16 + bf16g_gemm (in_x at sample rate) + bf16_layer_kernel<gx> x 6 + fused backward (bl6_layer_bwd<gx> x 6, "
+        "bl6_wgrad incl. 24 in_x jobs) + bf16g_gemm (d xm) + xm_bwd16", do_prob=0.5)
     add("cfg4_bl6_step_bf16_b64", train_leg, "the same step at 8x the batch: BL6, 64 x 16 500, mixed precision", bl6, dev, 64, 150,
         "bf16", 3, "bf16 forward + fused backward (bl6_head_bwd / bl6_layer_bwd x 7 / bl6_wgrad) + unfold_grads")
     return legs
