@@ -152,17 +152,27 @@ def cpu_model() -> str:
 
 
 def _hip_timed(fn, reps: int, warm: int = 1):
-    """mean ms per call, HIP events on torch's current stream (the stream every launch helper uses)."""
+    """mean ms per call over `reps` back-to-back calls, HIP events on torch's current stream (the stream every launch
+    helper uses).  A block that takes under 50 ms is measured three times and the median block is reported: one host
+    hiccup between two launches (an allocator refill, a page fault) otherwise lands whole in a 10-call mean (seen once:
+    the 0.88 ms fp32 forward leg read 5.2 ms)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+
+    def block():
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1)
+
+    t = block()
+    if t < 50.0:
+        t = sorted([t, block(), block()])[1]
+    return t / reps
 
 
 def _hbm(bytes_per_launch: float, ms: float, **extra):
