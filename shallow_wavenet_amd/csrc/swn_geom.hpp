@@ -160,6 +160,13 @@ static inline __host__ int swn_a0x(const SwnGeom* g) { return (g->A0 + 31) & ~31
 // dropout (H a multiple of 64): smaller nets keep the exact-fp32 forward, only their contractions of the backward are rounded.
 static inline __host__ bool swn_drop_bf16_forward(const SwnGeom* g) { return g->Hp == g->H && (g->H % 64) == 0; }
 
+// ... and, for seg == 1 at such nets, the three sample-rate in_x contractions of the dropout chain (forward product, weight
+// gradient, data gradient over every layer's kept d gx) read bf16 COPIES of their operands - the masked conditioning xm, d gx and
+// the in_x matrix - instead of rounding fp32 tensors on the way into LDS: the same products (the rounding is the one the fp32
+// route applies while staging), half the operand bytes, the kernels of the layer gradients.  Rows of swn_pitch16() elements.
+static inline __host__ bool swn_drop_inx16(const SwnGeom* g, long Tp) { return swn_drop_bf16_forward(g) && g->seg == 1 && Tp >= 256; }
+static inline __host__ long swn_pitch16(long T) { return (T + 2 + 31) & ~31L; }
+
 // BL6 class, mixed-precision mode, dropout as run.sh trains it (dilation_repeat == 1: the only hidden-state mask lands on the
 // last layer's output, which feeds nothing, so aux_drop is the one mask that acts - cswnv_shift1.py:194-195,211-217): the
 // forward work buffer of the fused path (csrc/swn_stack_bf16.hip: swn_bl6_drop_forward; read back by swn_bl6_bwd_stack).

@@ -291,6 +291,19 @@ __global__ __launch_bounds__(256) void xm_fwd_kernel(const float* __restrict__ C
     xm[ox] = drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]);
 }
 
+// the same as bf16 rows of `pitch` elements (swn_drop_inx16: operand of the bf16-copy contraction kernels, csrc/swn_train.hip)
+__global__ __launch_bounds__(256) void xm_fwd16_kernel(const float* __restrict__ C, const float* __restrict__ P, size_t wup, size_t bup,
+                                                       const float* __restrict__ drop_x, unsigned short* __restrict__ xm16,
+                                                       int A0, int A0x, int Tf, int U, int coff, int Tx, long pitch) {
+    const int u = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
+    if (u >= Tx) return;
+    unsigned short* dst = xm16 + ((size_t)b * A0x + c) * pitch + u;
+    if (c >= A0) { *dst = 0; return; }
+    const int tt = u + coff, f = tt / U, j = tt - f * U;
+    const size_t o = ((size_t)b * A0 + c) * Tx + u;
+    *dst = (unsigned short)(swn_pack_bf16(drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]), 0.f) & 0xffffu);
+}
+
 }  // namespace
 
 // relu(skip), relu(out_1) from the hidden states in `work` through the contraction kernels of the training mode (csrc/swn_train.hip)
@@ -301,7 +314,7 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
                                   hipStream_t st);
 // sample-rate in_x of every layer over the masked conditioning (csrc/swn_train.hip: generic time GEMM)
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
-                          int B, int Tx, int Tp, hipStream_t st);
+                          int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16 = nullptr);
 // BL6 class, mixed-precision mode, aux_drop the only mask that acts: the fused path (csrc/swn_stack_bf16.hip)
 int swn_bl6_drop_forward(const SwnGeom& g, const float* packed, const float* C, const float* audio, const float* drop_x,
                          int batch, int n_frames, void* work, float* out, hipStream_t st);
@@ -354,9 +367,18 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         size_t fe_off = (size_t)g.n_aux;                         // frame-rate activations: scaled | conv_aux layers
         for (int i = 0; i + 1 < g.auxl; ++i) fe_off += g.aux_cout[i];
         const float* C = fe_work + fe_off * (size_t)batch * n_frames;
+        unsigned short* wx16 = nullptr;
+        if (swn_call_mode() == SWN_PRECISION_BF16 && swn_drop_inx16(&g, Tp)) {
+            // xm as bf16 rows in the same section (the backward of the same mode reads them there), the bf16 in_x matrix at the
+            // end of the work buffer
+            wx16 = reinterpret_cast<unsigned short*>(gx + r64((size_t)batch * g.L * 2 * g.H * Tp) +
+                                                     (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp));
+            hipLaunchKernelGGL(xm_fwd16_kernel, dim3((Tx + 255) / 256, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
+                               drop_x, reinterpret_cast<unsigned short*>(xm), g.A0, swn_a0x(&g), n_frames, g.U, a.coff, Tx, swn_pitch16(Tx));
+        } else
         hipLaunchKernelGGL(xm_fwd_kernel, dim3((Tx + 255) / 256, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
                            drop_x, xm, g.A0, swn_a0x(&g), n_frames, g.U, a.coff, Tx);
-        rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st);
+        rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st, wx16);
         if (rc < 0) return rc;
         a.gx = gx;
     }
@@ -426,7 +448,8 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     // xm | gx | (mixed-precision forward) gate pre-activations of every layer | masked input of one layer
     const size_t chain = base + r64((size_t)batch * swn_a0x(&g) * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
-                         (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp);
+                         (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp) +
+                         r64((size_t)g.L * 2 * g.H * swn_a0x(&g) / 2 + 1);        // bf16 in_x matrix (swn_drop_inx16)
     const size_t fused = g.bl6 ? (swn_bl6_drop_layout(g, batch, Tp).total + 3) / 4 : 0;      // the fused BL6 path's own layout
     return chain > fused ? chain : fused;
 }

@@ -387,26 +387,30 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
 // column pair (2 tp, 2 tp + 1) of eight k rows: eight dword loads per k-tile, two byte-permutes per LDS store).  24 operand
 // registers per thread instead of 64 put THREE workgroups on a CU (launch bound) - these loops wait on memory round trips, and
 // what fewer bytes buy is workgroups in flight (bf16 X alone, registers unchanged, had gained nothing).
+// MT = 16-row accumulator tiles per wave: the workgroup tile is 32 MT rows x 128 positions.  M = 192 (the run.sh Laplace net) in
+// 128-row tiles left the second row tile half empty - a quarter of the MFMAs and of the A traffic on zeros; 96-row tiles fit.
+template <int MT>
 __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g) {
+    constexpr int RM = 32 * MT;
     __shared__ __attribute__((aligned(16))) unsigned As2[2][128][SWN_MMB_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned Bs2[2][128][SWN_MMB_PITCH];
-    const int ntt = (g.T + 127) / 128, mtl = (g.M + 127) / 128;
+    const int ntt = (g.T + 127) / 128, mtl = (g.M + RM - 1) / RM;
     const int chunk = (ntt * g.nb + 7) / 8;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
     const int ttl = idx / mtl, mtile = idx - ttl * mtl;
     const int gt = xcd * chunk + ttl;
     if (ttl >= chunk || gt >= ntt * g.nb) return;
-    const int b = gt / ntt, t0 = (gt - b * ntt) * 128, m0 = mtile * 128;
+    const int b = gt / ntt, t0 = (gt - b * ntt) * 128, m0 = mtile * RM;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.A16), 0, 0x40000000, 0x00020000);
     const __amdgpu_buffer_rsrc_t rX = rsrc_of(g.X16 + (size_t)b * g.x16_sb);
     const int ntiles = g.taps * (g.KC / 32);
-    swn_f32x4 acc[4][4] = {};
+    swn_f32x4 acc[MT][4] = {};
     const int XT = g.XT ? g.XT : g.T;
     const int a8 = tid & 3, ar0 = tid >> 2;                    // A: k-octet a8 of rows ar0, ar0 + 64
     unsigned arow[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { const int m = m0 + ar0 + 64 * i; arow[i] = m < g.M ? (unsigned)((m * g.a16_sm + 8 * a8) * 2) : SWN_OOB_A; }
+    for (int i = 0; i < 2; ++i) { const int m = m0 + ar0 + 64 * i; arow[i] = (m < g.M && ar0 + 64 * i < RM) ? (unsigned)((m * g.a16_sm + 8 * a8) * 2) : SWN_OOB_A; }
     const int tp = tid & 63, kw = tid >> 6;                    // X: column pair tp, k-quads kw and kw + 4
     const unsigned rs2 = (unsigned)(g.x16_sc * 2);
     int ftap = 0, fc0 = 0;
@@ -443,14 +447,13 @@ __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g)
     };
     auto mma = [&](int buf) {
         const int kq = lane >> 4, rc = lane & 15;
-        swn_bf16x8 fa[4], fb[4];
+        swn_bf16x8 fa[MT], fb[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            fa[i] = *reinterpret_cast<const swn_bf16x8*>(&As2[buf][64 * wm + 16 * i + rc][4 * kq]);
-            fb[i] = *reinterpret_cast<const swn_bf16x8*>(&Bs2[buf][64 * wn + 16 * i + rc][4 * kq]);
-        }
+        for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const swn_bf16x8*>(&As2[buf][16 * MT * wm + 16 * i + rc][4 * kq]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const swn_bf16x8*>(&Bs2[buf][64 * wn + 16 * i + rc][4 * kq]);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     };
@@ -467,19 +470,19 @@ __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g)
         mma(1);
     }
     const int kq = lane >> 4, rc = lane & 15;
-    int mrow[16];
+    int mrow[4 * MT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) mrow[4 * i + e] = m0 + 64 * wm + 16 * i + 4 * kq + e;
+        for (int e = 0; e < 4; ++e) mrow[4 * i + e] = m0 + 16 * MT * wm + 16 * i + 4 * kq + e;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        float v[16];
+        float v[4 * MT];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[4 * i + e] = acc[i][j][e];
-        tg_epilogue<16>(g, b, mrow, t0 + 64 * wn + 16 * j + rc, v);
+        tg_epilogue<4 * MT>(g, b, mrow, t0 + 64 * wn + 16 * j + rc, v);
     }
 }
 
@@ -914,6 +917,8 @@ struct GateBwd {
                                                // skip_da32: both GEMMs read the copies, the fp32 da is not stored
     unsigned short* h16; long h16_odd;         // optional: the layer's (masked) input as two bf16 copies like da16's (rows of
                                                // da16_pitch elements): the weight gradient's Q operand (ReduceGemm::Q16)
+    unsigned short* dgx16; long dgx16_sb;      // optional (swn_drop_inx16): d gx as bf16 rows of da16_pitch elements INSTEAD of the
+                                               // fp32 dgx - the operand of the two merged in_x contractions behind the layer loop
 };
 
 template <int KIND>
@@ -971,8 +976,14 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
         rz[0] = (unsigned short)(pk & 0xffffu); rz[a.da16_odd + 1] = (unsigned short)(pk & 0xffffu);
         rc[0] = (unsigned short)(pk >> 16); rc[a.da16_odd + 1] = (unsigned short)(pk >> 16);
     }
-    a.dgx[(size_t)b * a.dgx_sb + (size_t)o * a.Tp + t] = dz * sz;
-    a.dgx[(size_t)b * a.dgx_sb + (size_t)(H + o) * a.Tp + t] = dc * sc;
+    if (a.dgx16) {
+        const unsigned pk = swn_pack_bf16(dz * sz, dc * sc);
+        a.dgx16[(size_t)b * a.dgx16_sb + (size_t)o * a.da16_pitch + t] = (unsigned short)(pk & 0xffffu);
+        a.dgx16[(size_t)b * a.dgx16_sb + (size_t)(H + o) * a.da16_pitch + t] = (unsigned short)(pk >> 16);
+    } else {
+        a.dgx[(size_t)b * a.dgx_sb + (size_t)o * a.Tp + t] = dz * sz;
+        a.dgx[(size_t)b * a.dgx_sb + (size_t)(H + o) * a.Tp + t] = dc * sc;
+    }
     if (KIND == SWN_KIND_SOFTMAX && g.audio_in && a.gwxa) {      // one-hot input column idx: d in_x.W[o][A0+idx] += dgx
         atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + o, dz * sz);
         atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + H + o, dc * sc);
@@ -1247,7 +1258,12 @@ void launch_time(const TimeGemm& g, int B, hipStream_t st) {
             h.nb = B;
             const int chunk = (((g.T + 127) / 128) * B + 7) / 8;
             const dim3 big((unsigned)(8 * chunk * ((g.M + 127) / 128)));
-            if (g.A16 && g.X16 && !g.mask) hipLaunchKernelGGL(time_gemm_b16_kernel, big, dim3(256), 0, st, h);
+            if (g.A16 && g.X16 && !g.mask) {
+                // 96-row tiles where they cover M with fewer padded rows than 128-row tiles (M = 192: 2 x 96 against 128 + 64 of 128)
+                const int m96 = (g.M + 95) / 96, m128 = (g.M + 127) / 128;
+                if (m96 * 96 < m128 * 128) hipLaunchKernelGGL(time_gemm_b16_kernel<3>, dim3((unsigned)(8 * chunk * m96)), dim3(256), 0, st, h);
+                else hipLaunchKernelGGL(time_gemm_b16_kernel<4>, big, dim3(256), 0, st, h);
+            }
             else if (g.a_sc == 1) hipLaunchKernelGGL(time_gemm_bf16t_kernel<true>, big, dim3(256), 0, st, h);
             else hipLaunchKernelGGL(time_gemm_bf16t_kernel<false>, big, dim3(256), 0, st, h);
             return;
@@ -1584,14 +1600,36 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
     return SWN_OK;
 }
 
+// bf16 copies of the in_x matrix [N][A0p] (seg == 1: row n = l*2H + o) for the bf16-copy contraction kernels (swn_drop_inx16):
+// rows[n][c] over the A0x = 32-aligned conditioning rows (zeros from A0 on) for the forward product, and / or the transpose
+// cols[c][n] for the data gradient
+namespace {
+__global__ __launch_bounds__(256) void wx16_kernel(const float* __restrict__ wx, const int N, const int A0, const int A0p, const int A0x,
+                                                   unsigned short* __restrict__ rows, unsigned short* __restrict__ cols) {
+    const size_t n_el = (size_t)N * A0x;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < n_el; e += (size_t)gridDim.x * 256) {
+        const int n = (int)(e / A0x), c = (int)(e - (size_t)n * A0x);
+        const unsigned short v = c < A0 ? (unsigned short)(swn_pack_bf16(wx[(size_t)n * A0p + c], 0.f) & 0xffffu) : (unsigned short)0;
+        if (rows) rows[e] = v;
+        if (cols) cols[(size_t)c * N + n] = v;
+    }
+}
+}  // namespace
+
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
-                          int B, int Tx, int Tp, hipStream_t st) {
+                          int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16) {
     const int H2 = 2 * g.H;
     if (g.seg == 1) {                 // one launch over the L * 2H rows of the [N][A0p] matrix (row n = l*2H + o): gx is (B, L*2H, Tp)
         const int A0x = swn_a0x(&g);
         TimeGemm t = {packed + y.wx, g.A0p, 0, 1, xm, (long)A0x * Tx, Tx, 1, gx, (long)g.L * H2 * Tp, Tp, nullptr, 0, 0,
                       g.L * H2, 1, A0x, Tp, 1, 0, 1, 0};
         t.XT = Tx;
+        if (wx16) {                   // swn_drop_inx16: xm holds bf16 rows of swn_pitch16(Tx) elements, wx16 receives the bf16 matrix
+            hipLaunchKernelGGL(wx16_kernel, dim3(512), dim3(256), 0, st, packed + y.wx, g.L * H2, g.A0, g.A0p, A0x, wx16, nullptr);
+            const long px = swn_pitch16(Tx);
+            t.A16 = wx16; t.a16_sm = A0x; t.a16_stap = 0;
+            t.X16 = reinterpret_cast<const unsigned short*>(xm); t.x16_sb = (long)A0x * px; t.x16_sc = px; t.x16_odd = 0;
+        }
         launch_time(t, B, st);
         return SWN_OK;
     }
@@ -1756,6 +1794,11 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     // the masked conditioning is ONE contraction over the L * 2H rows of in_x behind the loop instead of L read-modify-write
     // passes over d xm (257 MB each way at the run.sh geometry)
     float* dgx_all = (drop && !drop_fused && g.seg == 1) ? work + drop_chain_floats(g, B, n_frames) : nullptr;
+    // swn_drop_inx16 (the forward of the same mode left xm as bf16 rows): d gx is kept as bf16 rows in that section instead, and the
+    // transposed bf16 in_x matrix sits behind it
+    const bool inx16 = dgx_all && !hs_opt && mode_bf16() && da16 && swn_drop_inx16(&g, Tp);
+    unsigned short* dgx16_all = inx16 ? reinterpret_cast<unsigned short*>(dgx_all) : nullptr;
+    unsigned short* wxt16 = inx16 ? reinterpret_cast<unsigned short*>(dgx_all + r64((size_t)B * L * H2 * Tp)) : nullptr;
     ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
     ga.gx = drop ? gx : nullptr;
     ga.gwxa = g.audio_in ? gpacked + y.wxa : nullptr;
@@ -1773,6 +1816,7 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     for (int l = hs_bf16 ? -1 : L - 1; l >= 0; --l) {
         ga.l = l;
         if (dgx_all) { dgx = dgx_all + (size_t)l * H2 * Tp; ga.dgx = dgx; ga.dgx_sb = (long)L * H2 * Tp; }
+        if (dgx16_all) { ga.dgx16 = dgx16_all + (size_t)l * H2 * da16_pitch; ga.dgx16_sb = (long)L * H2 * da16_pitch; }
         // dropout mode: this layer's input is h_{l-1} times the mask drawn for layer l-1's output (cswnv_shift1.py:269-273)
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;
         ga.in_mul = in_mul;
@@ -1844,11 +1888,21 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         ReduceGemm r = {dgx_all, (long)L * H2 * Tp, Tp, 1, xm, (long)swn_a0x(&g) * Tx, Tx, 1, gpacked + y.wx, g.A0p, 0, 1,
                         gpacked + y.bxr, L * H2, 1, g.A0, Tp, 1, 0, 1, 0};
         r.QT = Tx;
+        if (inx16) {
+            const long px = swn_pitch16(Tx);
+            r.P16 = dgx16_all; r.p16_sb = (long)L * H2 * da16_pitch; r.p16_sm = da16_pitch;
+            r.Q16 = reinterpret_cast<const unsigned short*>(xm); r.q16_sb = (long)swn_a0x(&g) * px; r.q16_sc = px; r.q16_odd = 0;
+        }
         launch_reduce(r, B, st);
         // dxm[c][u] = sum_n in_x.W[n][c] dgx[n][u]
         TimeGemm t = {packed + y.wx, 1, 0, g.A0p, dgx_all, (long)L * H2 * Tp, Tp, 1, dxm, (long)g.A0 * Tx, Tx, nullptr, 0, 0,
                       g.A0, 1, L * H2, Tx, -1, 0, 1, 0};
         t.XT = Tp;
+        if (inx16) {
+            hipLaunchKernelGGL(wx16_kernel, dim3(512), dim3(256), 0, st, packed + y.wx, L * H2, g.A0, g.A0p, swn_a0x(&g), nullptr, wxt16);
+            t.A16 = wxt16; t.a16_sm = L * H2; t.a16_stap = 0;
+            t.X16 = dgx16_all; t.x16_sb = (long)L * H2 * da16_pitch; t.x16_sc = da16_pitch; t.x16_odd = 0;
+        }
         launch_time(t, B, st);
     }
     if (wup_part) hipLaunchKernelGGL(wup_fold_kernel, dim3(1), dim3(256), 0, st, wup_part, gpacked + y.wup, g.U);
@@ -1957,7 +2011,8 @@ extern "C" size_t swn_backward_drop_work_floats(const swn_net_desc* d, int batch
     const long T = (long)n_frames * g.U;
     const long Tp = g.kind == SWN_KIND_SOFTMAX ? T - 1 : T - 2 * g.seg + 1;
     // the generic chain's layout, + (seg == 1) every layer's d gx behind it
-    const size_t chain = drop_chain_floats(g, batch, n_frames) + (g.seg == 1 ? r64((size_t)batch * g.L * 2 * g.H * Tp) : 0);
+    const size_t chain = drop_chain_floats(g, batch, n_frames) + (g.seg == 1 ? r64((size_t)batch * g.L * 2 * g.H * Tp) +
+                                                                   r64((size_t)swn_a0x(&g) * g.L * 2 * g.H / 2 + 1) : 0);   // + transposed bf16 in_x matrix
     size_t fused = 0;                                  // the fused BL6 path: d cond (unused) | front-end gradients | d xm | its scratch
     if (g.kind == SWN_KIND_LAPLACE && swn_bl6_bwd_supported(g, batch, Tp, n_frames)) {
         size_t fw = (size_t)g.n_aux; for (int i = 0; i < g.auxl; ++i) fw += g.aux_cout[i];
