@@ -382,18 +382,28 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
 }
 
 
-// Data gradients with BOTH operands in bf16 (mixed-precision chain at the GEMM-stack geometries): A from a transposed bf16 copy of
-// the layer matrix (16-byte loads of eight k straight into LDS), X from gate_bwd's two bf16 copies of da (a thread owns the
-// column pair (2 tp, 2 tp + 1) of eight k rows: eight dword loads per k-tile, two byte-permutes per LDS store).  24 operand
-// registers per thread instead of 64 put THREE workgroups on a CU (launch bound) - these loops wait on memory round trips, and
-// what fewer bytes buy is workgroups in flight (bf16 X alone, registers unchanged, had gained nothing).
+// Time contraction with BOTH operands in bf16 (mixed-precision chain at the GEMM-stack geometries: the layer data gradients, and
+// the in_x products of the dropout chain): A from a bf16 matrix whose k axis is contiguous (16-byte loads of eight k straight into
+// LDS), X from bf16 rows [channel][t] - t contiguous, i.e. the k axis of the product is the STRIDED one.  A k-tile of X (32 channel
+// rows x 128 positions) is staged exactly as it lies in memory - two 16-byte loads per thread, eight lanes = one 128-byte row
+// segment, 16-byte LDS stores - and the MFMA B fragments (eight consecutive k of one position) are gathered by the transposing
+// LDS read ds_read_b64_tr_b16 (two per fragment).  The first form of this kernel gave a thread a column pair of eight k rows:
+// eight dword loads per k-tile and two byte-permutes per LDS store - 32 load instructions per workgroup and k-tile where this
+// form issues 8.  An odd tap shift reads the second copy of X (moved right by one position: x16_odd), so that every 16-byte
+// piece starts on a dword.  LDS image: rows of 256 bytes, the 32-byte chunk pairs of row r XOR-swizzled by (r & 3) | ((r >> 3) & 1) << 2:
+// the eight rows a transposed read touches per 32-lane half land on eight different bank groups.
+// The buffer view of X starts 16 bytes before the operand (a piece that straddles position 0 has a negative offset): X16 must
+// not be the first bytes of an allocation (it never is: the copies live inside the work buffers).
+// 16 operand registers per thread and stage; three workgroups per CU (launch bound) - these loops wait on memory round trips.
 // MT = 16-row accumulator tiles per wave: the workgroup tile is 32 MT rows x 128 positions.  M = 192 (the run.sh Laplace net) in
 // 128-row tiles left the second row tile half empty - a quarter of the MFMAs and of the A traffic on zeros; 96-row tiles fit.
+typedef short swn_s16x4 __attribute__((ext_vector_type(4)));
+typedef short swn_s16x8 __attribute__((ext_vector_type(8)));
 template <int MT>
 __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g) {
     constexpr int RM = 32 * MT;
     __shared__ __attribute__((aligned(16))) unsigned As2[2][128][SWN_MMB_PITCH];
-    __shared__ __attribute__((aligned(16))) unsigned Bs2[2][128][SWN_MMB_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned char Xs2[2][32 * 256];
     const int ntt = (g.T + 127) / 128, mtl = (g.M + RM - 1) / RM;
     const int chunk = (ntt * g.nb + 7) / 8;
     const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -403,7 +413,7 @@ __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g)
     const int b = gt / ntt, t0 = (gt - b * ntt) * 128, m0 = mtile * RM;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, wm = w >> 1, wn = w & 1;
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(g.A16), 0, 0x40000000, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rX = rsrc_of(g.X16 + (size_t)b * g.x16_sb);
+    const __amdgpu_buffer_rsrc_t rX = rsrc_of(g.X16 + (size_t)b * g.x16_sb - 8);      // every X offset below carries + 8 elements
     const int ntiles = g.taps * (g.KC / 32);
     swn_f32x4 acc[MT][4] = {};
     const int XT = g.XT ? g.XT : g.T;
@@ -411,65 +421,82 @@ __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g)
     unsigned arow[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const int m = m0 + ar0 + 64 * i; arow[i] = (m < g.M && ar0 + 64 * i < RM) ? (unsigned)((m * g.a16_sm + 8 * a8) * 2) : SWN_OOB_A; }
-    const int tp = tid & 63, kw = tid >> 6;                    // X: column pair tp, k-quads kw and kw + 4
+    const int xr = tid >> 3, xc = tid & 7;                     // X: k row xr of the tile, 16-byte pieces xc and xc + 8 of its 128 positions
     const unsigned rs2 = (unsigned)(g.x16_sc * 2);
+    unsigned xdst[2];
+    {
+        const int sw = (xr & 3) | (((xr >> 3) & 1) << 2);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { const int c = xc + 8 * i; xdst[i] = (unsigned)(xr * 256 + (((((c >> 1) ^ sw) << 1) | (c & 1)) << 4)); }
+    }
     int ftap = 0, fc0 = 0;
-    swn_fl4 ra[2][2]; unsigned rb[2][8];
-    auto fetch = [&](swn_fl4 (&qa)[2], unsigned (&qb)[8]) {
+    swn_fl4 ra[2][2], rb[2][2]; int rsh[2];
+    auto fetch = [&](swn_fl4 (&qa)[2], swn_fl4 (&qb)[2], int& qsh) {
         const bool live = fc0 < g.KC;
         const unsigned sA = live ? (unsigned)((ftap * g.a16_stap + fc0) * 2) : SWN_OOB;
 #pragma unroll
         for (int i = 0; i < 2; ++i) qa[i] = bld4(rA, arow[i] + sA);
         const int sh = g.sgn * (ftap - g.center) * g.dil, par = sh & 1;
-        const int ts = t0 + 2 * tp + sh;                                       // source positions ts, ts + 1
-        const bool ok0 = live && ts >= 0 && ts < XT, ok1 = live && ts + 1 >= 0 && ts + 1 < XT;
-        // even shift: dword (ts, ts + 1) of the plain copy; odd: dword at index ts + 1 of the copy moved right by one
-        const unsigned base = (ok0 || ok1) ? (unsigned)(((par ? g.x16_odd + 1 : 0) + ts) * 2) : SWN_OOB;
-        const unsigned mk = (ok0 ? 0x0000ffffu : 0u) | (ok1 ? 0xffff0000u : 0u);
+        qsh = sh;
+        // even shift: positions ts .. ts + 7 of the plain copy; odd: elements ts + 1 .. of the copy moved right by one (a dword start)
+        const unsigned rowb = (unsigned)(fc0 + xr) * rs2 + (unsigned)(((par ? g.x16_odd + 1 : 0) + 8) * 2);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                qb[4 * i + e] = __float_as_uint(bld1(rX, base + (unsigned)(fc0 + 4 * (kw + 4 * i) + e) * rs2)) & mk;
+        for (int i = 0; i < 2; ++i) {
+            const int ts = t0 + 8 * (xc + 8 * i) + sh;
+            qb[i] = bld4(rX, (live && ts + 7 >= 0 && ts < XT) ? rowb + (unsigned)(ts * 2) : SWN_OOB);
+        }
         if (++ftap >= g.taps) { ftap = 0; fc0 += 32; }         // taps innermost, as in time_gemm_bf16t_kernel
     };
-    auto stage = [&](int buf, const swn_fl4 (&qa)[2], const unsigned (&qb)[8]) {
-        typedef unsigned u2 __attribute__((ext_vector_type(2)));
+    auto stage = [&](int buf, const swn_fl4 (&qa)[2], swn_fl4 (&qb)[2], const int sh) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<swn_fl4*>(&As2[buf][ar0 + 64 * i][4 * a8]) = qa[i];
-            const unsigned d0 = qb[4 * i], d1 = qb[4 * i + 1], d2 = qb[4 * i + 2], d3 = qb[4 * i + 3];   // d_e = (x[k e][2 tp], x[k e][2 tp + 1])
-            const u2 lo = {(d0 & 0xffffu) | (d1 << 16), (d2 & 0xffffu) | (d3 << 16)};
-            const u2 hi = {(d0 >> 16) | (d1 & 0xffff0000u), (d2 >> 16) | (d3 & 0xffff0000u)};
-            *reinterpret_cast<u2*>(&Bs2[buf][2 * tp][2 * (kw + 4 * i)]) = lo;
-            *reinterpret_cast<u2*>(&Bs2[buf][2 * tp + 1][2 * (kw + 4 * i)]) = hi;
+            const int ts = t0 + 8 * (xc + 8 * i) + sh;
+            if (ts < 0 || ts + 8 > XT) {                       // rare: the piece straddles an end of the sequence
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const int e0 = ts + 2 * d, e1 = e0 + 1;
+                    const unsigned mk = ((e0 >= 0 && e0 < XT) ? 0x0000ffffu : 0u) | ((e1 >= 0 && e1 < XT) ? 0xffff0000u : 0u);
+                    qb[i][d] = __uint_as_float(__float_as_uint(qb[i][d]) & mk);
+                }
+            }
+            *reinterpret_cast<swn_fl4*>(&Xs2[buf][xdst[i]]) = qb[i];
         }
     };
+    // transposed-read addresses of this lane: lane 4q + p of the 16-lane group kq supplies row 8 kq + 4 h + q, bytes 8 p .. 8 p + 7 of
+    // the 32-byte chunk pair of n-tile J (swizzled by the row)
+    const int kq = lane >> 4, rc = lane & 15;
+    const unsigned trb = (unsigned)((8 * kq + (rc >> 2)) * 256 + ((rc & 3) << 3));
+    const int trs = (rc >> 2) | ((kq & 1) << 2);
     auto mma = [&](int buf) {
-        const int kq = lane >> 4, rc = lane & 15;
         swn_bf16x8 fa[MT], fb[4];
 #pragma unroll
         for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const swn_bf16x8*>(&As2[buf][16 * MT * wm + 16 * i + rc][4 * kq]);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fb[i] = *reinterpret_cast<const swn_bf16x8*>(&Bs2[buf][64 * wn + 16 * i + rc][4 * kq]);
+        for (int j = 0; j < 4; ++j) {
+            const unsigned char* src = &Xs2[buf][trb + (unsigned)(((4 * wn + j) ^ trs) << 5)];
+            const swn_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) swn_s16x4*)(src));
+            const swn_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) swn_s16x4*)(src + 4 * 256));
+            const swn_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            fb[j] = __builtin_bit_cast(swn_bf16x8, v);
+        }
 #pragma unroll
         for (int i = 0; i < MT; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     };
-    fetch(ra[0], rb[0]);
-    fetch(ra[1], rb[1]);
+    fetch(ra[0], rb[0], rsh[0]);
+    fetch(ra[1], rb[1], rsh[1]);
     for (int j = 0; j < ntiles; j += 2) {                      // a tile past the end is all zeros
-        stage(0, ra[0], rb[0]);
+        stage(0, ra[0], rb[0], rsh[0]);
         __syncthreads();                                       // every wave is past the MFMAs that read this buffer two tiles ago
-        fetch(ra[0], rb[0]);
+        fetch(ra[0], rb[0], rsh[0]);
         mma(0);
-        stage(1, ra[1], rb[1]);
+        stage(1, ra[1], rb[1], rsh[1]);
         __syncthreads();
-        fetch(ra[1], rb[1]);
+        fetch(ra[1], rb[1], rsh[1]);
         mma(1);
     }
-    const int kq = lane >> 4, rc = lane & 15;
     int mrow[4 * MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
