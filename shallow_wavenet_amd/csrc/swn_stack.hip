@@ -315,11 +315,29 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
 // sample-rate in_x of every layer over the masked conditioning (csrc/swn_train.hip: generic time GEMM)
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
                           int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16 = nullptr);
+// GEMM-stack geometries, mixed-precision mode: the dropout-mode forward on the bf16 time-major stack (csrc/swn_stack_bf16g.hip)
+int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g);
+size_t swn_bf16g_weight_bytes(const SwnGeom& g);
+int swn_bf16g_pack(const SwnGeom& g, const float* packed, void* wbf, hipStream_t st);
+size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
+int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, bool hs_only, hipStream_t st);
+int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const void* audio,
+                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep,
+                      const float* gx, const float* const* drop_h, unsigned short* hm16);
 // BL6 class, mixed-precision mode, aux_drop the only mask that acts: the fused path (csrc/swn_stack_bf16.hip)
 int swn_bl6_drop_forward(const SwnGeom& g, const float* packed, const float* C, const float* audio, const float* drop_x,
                          int batch, int n_frames, void* work, float* out, hipStream_t st);
 
 namespace {
+
+// does the dropout-mode forward of the mixed-precision mode run on the bf16 time-major GEMM stack?  (the geometry class of
+// csrc/swn_stack_bf16g.hip, its 32-bit operand offsets, a sequence long enough for the bf16-copy contractions)
+bool drop_g16(const swn_net_desc* d, int batch, long Tp) {
+    SwnGeom g;
+    if (swn_bf16g_geom(d, &g) != SWN_OK || Tp < 256) return false;
+    const size_t lstride = (size_t)batch * Tp * g.H;
+    return (size_t)g.L * lstride * 2 < (1ull << 31) && (size_t)batch * Tp * (g.S > g.O1 ? g.S : g.O1) * 2 < (1ull << 31);
+}
 
 int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, const float* fe_work, const void* audio,
                  int batch, int n_frames, const float* drop_x, const float* const* drop_h, float* work, float* out,
@@ -381,6 +399,24 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st, wx16);
         if (rc < 0) return rc;
         a.gx = gx;
+    }
+    if (drop && !hs && swn_call_mode() == SWN_PRECISION_BF16 && drop_g16(d, batch, Tp)) {
+        // GEMM-stack geometries: input layer, gated layers (gate epilogue on the sample-rate in_x rows, a dropped level read through
+        // its masked copy, pre-activations kept for the backward) and head on the bf16 time-major stack of the forward without
+        // dropout; what the backward reads in fp32 (hidden states, relu(skip), relu(out_1)) is expanded from it.  Replaces one
+        // fp32-operand time GEMM + one element-wise gate launch per layer (475 -> ~330 us per layer at the run.sh geometry).
+        float* a_scr = const_cast<float*>(a.gx) + r64((size_t)batch * g.L * 2 * g.H * Tp);
+        float* tail = a_scr + (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp) +
+                      r64((size_t)g.L * 2 * g.H * swn_a0x(&g) / 2 + 1);
+        void* work16 = tail;
+        unsigned short* hm16 = reinterpret_cast<unsigned short*>(tail + r64((swn_bf16g_work_bytes(g, batch, Tp) + 3) / 4));
+        void* wbf = reinterpret_cast<float*>(hm16) + r64((size_t)batch * Tp * g.H / 2 + 1);
+        rc = swn_bf16g_pack(g, packed, wbf, st);
+        if (rc < 0) return rc;
+        rc = swn_bf16g_forward(g, packed, wbf, nullptr, audio, batch, n_frames, work16, out, st, a_scr, a.gx, drop_h, hm16);
+        if (rc < 0) return rc;
+        rc = swn_bf16g_expand(g, work16, batch, Tp, work, false, st);
+        return rc < 0 ? rc : swn_launch_status(where);
     }
     const int tb64 = (int)((Tp + 63) / 64);
     {
@@ -449,7 +485,9 @@ extern "C" size_t swn_forward_drop_work_floats(const swn_net_desc* d, int batch,
     // xm | gx | (mixed-precision forward) gate pre-activations of every layer | masked input of one layer
     const size_t chain = base + r64((size_t)batch * swn_a0x(&g) * (T - coff)) + r64((size_t)batch * g.L * 2 * g.H * Tp) +
                          (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp) +
-                         r64((size_t)g.L * 2 * g.H * swn_a0x(&g) / 2 + 1);        // bf16 in_x matrix (swn_drop_inx16)
+                         r64((size_t)g.L * 2 * g.H * swn_a0x(&g) / 2 + 1) +       // bf16 in_x matrix (swn_drop_inx16)
+                         (drop_g16(d, batch, Tp) ? r64((swn_bf16g_work_bytes(g, batch, Tp) + 3) / 4) + r64((size_t)batch * Tp * g.H / 2 + 1) +
+                                                       r64((swn_bf16g_weight_bytes(g) + 3) / 4) : 0);    // bf16 stack | masked level | bf16 weights
     const size_t fused = g.bl6 ? (swn_bl6_drop_layout(g, batch, Tp).total + 3) / 4 : 0;      // the fused BL6 path's own layout
     return chain > fused ? chain : fused;
 }

@@ -1032,7 +1032,8 @@ size_t swn_bf16g_work_bytes(const SwnGeom& g, int batch, long Tp);
 int swn_bf16g_expand(const SwnGeom& g, const void* work, int batch, long Tp, float* fwd_work, bool hs_only, hipStream_t st);
 int swn_train_head_acts(const SwnGeom& g, const float* packed, float* work, int batch, long Tp, hipStream_t st);
 int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf, const float* cond, const void* audio,
-                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep = nullptr);
+                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep = nullptr,
+                      const float* gx = nullptr, const float* const* drop_h = nullptr, unsigned short* hm16 = nullptr);
 size_t swn_bf16g_keep_floats(const SwnGeom& g, int batch, long Tp);
 
 int swn_bf16g_plain(const unsigned short* A, int M, const unsigned short* src, size_t blk_stride, size_t src_bytes, int KB, int nblk,

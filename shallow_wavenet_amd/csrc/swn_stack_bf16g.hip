@@ -47,6 +47,8 @@ struct GemmArgs {
     const int* aidx; int Q;                        // softmax audio_in: class index of position t, or null
     int ntt, nmt;                                  // time tiles per utterance, row tiles (set by launch_gemm)
     float* a_out;                                  // gate: where to keep the pre-activations (B, 2H, Tp) fp32 for the backward, or null
+    const float* gx; size_t o_bxr; int gx_rows;    // gate, dropout mode: sample-rate in_x products (B, gx_rows = L*2H, Tp) fp32 (row l*2H + o)
+                                                   // instead of the hoisted cond, + the raw in_x bias (cswnv_shift1.py:194-198,269-278)
 };
 
 // Three workgroups per CU (launch bound: 138 registers, accumulators included) with two register stages beat two workgroups with
@@ -158,9 +160,18 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
                 const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
                 if (ch >= H) continue;
                 float gz[4], gc[4];
+                if (a.gx) {
+                    const float* gr = a.gx + ((size_t)b * a.gx_rows + (size_t)l * H2 + ch) * a.Tp + t;     // 64-byte runs along t, as a_out
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        gz[r] = gr[(size_t)r * a.Tp] + P[a.o_bxr + (size_t)l * H2 + ch + r];
+                        gc[r] = gr[(size_t)(H + r) * a.Tp] + P[a.o_bxr + (size_t)l * H2 + H + ch + r];
+                    }
+                } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { gz[r] = P[a.o_bx + (size_t)l * H2 + ch + r]; gc[r] = P[a.o_bx + (size_t)l * H2 + H + ch + r]; }
-                for (int s = 0; s < a.seg; ++s) {
+                }
+                for (int s = 0; s < (a.gx ? 0 : a.seg); ++s) {
                     const int tt = t + s + a.coff;
                     int f = tt / a.U; const int jj = tt - f * a.U;
                     f = f < a.Tf ? f : a.Tf - 1;
@@ -322,6 +333,39 @@ __global__ __launch_bounds__(256) void bf16g_input_softmax_kernel(const float* _
     }
 }
 
+// dropout mode: a dropped layer's output as the NEXT layer reads it (conv operand and highway term): dst[b][t][c] =
+// src[b][t][c] * mask[b][c][t] (bf16 time-major rows x the reference's (B, H, Tp) fp32 mask; 0 or 1/(1-p), a power of two: exact).
+// 64 positions x 64 channels per workgroup, the mask tile transposed through LDS.
+__global__ __launch_bounds__(256) void bf16g_mask_kernel(const unsigned short* __restrict__ src, const float* __restrict__ mask,
+                                                         unsigned short* __restrict__ dst, int H, int Tp) {
+    __shared__ float tile[64][65];
+    const int b = blockIdx.z, t0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tid = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int c = (tid >> 6) + 4 * i, t = tid & 63;
+        tile[c][t] = (c0 + c < H && t0 + t < Tp) ? mask[((size_t)b * H + c0 + c) * Tp + t0 + t] : 0.f;
+    }
+    __syncthreads();
+    const int t = tid >> 2, cq = (tid & 3) * 16;
+    if (t0 + t >= Tp) return;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int c = c0 + cq + 8 * h;
+        if (c >= H) break;                                           // H % 8 == 0
+        const size_t o = ((size_t)b * Tp + t0 + t) * H + c;
+        const uint4 v = *reinterpret_cast<const uint4*>(src + o);
+        const unsigned u[4] = {v.x, v.y, v.z, v.w};
+        unsigned r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float lo = bf2f((unsigned short)(u[j] & 0xffff)) * tile[cq + 8 * h + 2 * j][t];
+            const float hi = bf2f((unsigned short)(u[j] >> 16)) * tile[cq + 8 * h + 2 * j + 1][t];
+            r[j] = f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+        }
+        *reinterpret_cast<uint4*>(dst + o) = make_uint4(r[0], r[1], r[2], r[3]);
+    }
+}
+
 struct GOff { size_t wd, wsk, w1, w2, total; };
 GOff g_offsets(const SwnGeom& g) {
     GOff o;
@@ -455,8 +499,12 @@ size_t swn_bf16g_keep_floats(const SwnGeom& g, int batch, long Tp) {
     return (size_t)g.L * (((size_t)batch * 2 * g.H * Tp + 63) & ~(size_t)63);
 }
 
+// gx != null: the dropout mode (cswnv_shift1.py:194-198,211-217,269-278) - sample-rate in_x products instead of the hoisted
+// cond, and drop_h[l] (device pointers, null = no mask) = the (B, H, Tp) mask on layer l's OUTPUT as the next layer reads it
+// (the skip GEMM reads the undropped states); hm16 = room for one masked level, B * Tp * H bf16
 int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, const float* cond, const void* audio,
-                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep) {
+                      int batch, int n_frames, void* work, float* out, hipStream_t st, float* a_keep,
+                      const float* gx, const float* const* drop_h, unsigned short* hm16) {
     SwnLayout y; swn_make_layout(&g, &y);
     const GOff o = g_offsets(g);
     const long Tp = (long)n_frames * g.U - 2 * g.seg + 1;
@@ -480,6 +528,7 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
     a.aidx = (g.kind == SWN_KIND_SOFTMAX && g.audio_in) ? reinterpret_cast<const int*>(audio) : nullptr; a.Q = g.Q; a.o_wxa = y.wxa;
     a.Tp = (int)Tp; a.B = batch; a.P = packed; a.cond = cond; a.H = g.H; a.seg = g.seg; a.U = g.U; a.Tf = n_frames; a.N = g.N;
     a.coff = g.seg; a.o_bd = y.bd; a.o_bx = y.bx; a.o_wup = y.wup;
+    a.gx = gx; a.o_bxr = y.bxr; a.gx_rows = g.L * 2 * g.H;
     constexpr int WNT = 4;                      // 128 x 128 workgroup tile (a 128 x 256 tile with 64 x 128 per wave needs 392 registers: one wave per SIMD, 1.4x slower)
     const unsigned tx = (unsigned)((Tp + 32 * WNT - 1) / (32 * WNT));
     for (int l = 0; l < g.L; ++l) {
@@ -487,6 +536,11 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
         a.src = hs + (size_t)l * lstride; a.blk_stride = 0; a.KB = g.H; a.nblk = g.K; a.src_bytes = lstride * 2;
         a.shift0 = (g.K - 1) * g.dil[l]; a.shift_step = g.dil[l];
         a.hprev = hs + (size_t)l * lstride; a.hnext = hs + (size_t)(l + 1) * lstride; a.l = l;
+        if (gx && drop_h && l > 0 && drop_h[l - 1]) {           // layer l-1's output was dropped: this layer reads the masked copy
+            hipLaunchKernelGGL(bf16g_mask_kernel, dim3((unsigned)((Tp + 63) / 64), (g.H + 63) / 64, batch), dim3(256), 0, st,
+                               hs + (size_t)l * lstride, drop_h[l - 1], hm16, g.H, (int)Tp);
+            a.src = hm16; a.hprev = hm16;
+        }
         a.a_out = a_keep ? a_keep + (size_t)l * (((size_t)batch * 2 * g.H * Tp + 63) & ~(size_t)63) : nullptr;
         launch_gemm<EPI_GATE>(a, (int)tx, g.H / 64, batch, st);
     }
