@@ -167,6 +167,20 @@ static inline __host__ bool swn_drop_bf16_forward(const SwnGeom* g) { return g->
 static inline __host__ bool swn_drop_inx16(const SwnGeom* g, long Tp) { return swn_drop_bf16_forward(g) && g->seg == 1 && Tp >= 256; }
 static inline __host__ long swn_pitch16(long T) { return (T + 2 + 31) & ~31L; }
 
+// "G4" layout of a (B, R, Tp) fp32 tensor that the MFMA epilogues of the mixed-precision GEMM-stack path write and read (R % 4 == 0):
+// blocks of 16 positions x all R rows; inside a block the rows go in groups of four, [row / 4][t % 16][row % 4]; the last block is
+// Tp % 16 positions wide (no padding: B * R * Tp floats like the plain layout).  An accumulator lane - four consecutive rows of one
+// position - is then ONE 16-byte piece and the 16 lanes of a column group 256 contiguous bytes, where the plain (B, R, Tp) layout
+// costs four 4-byte accesses in 64-byte runs (measured on the gated layer of the run.sh geometry: +65 us for storing the
+// pre-activations, +100 us for reading the sample-rate in_x rows, of 206).  Tensors in this layout: the kept gate
+// pre-activations of csrc/swn_stack_bf16g.hip and the in_x rows gx of the dropout mode when that stack runs the forward.
+static inline __host__ __device__ size_t swn_g4(int R, int Tp, int b, int row, int t) {
+    const int tb = t >> 4, wid = Tp - 16 * tb < 16 ? Tp - 16 * tb : 16;
+    return ((size_t)b * Tp + 16 * (size_t)tb) * R + ((size_t)(row >> 2) * wid + (t & 15)) * 4 + (row & 3);
+}
+// does the dropout-mode forward of the mixed-precision mode run on the bf16 time-major GEMM stack (csrc/swn_stack.hip)?
+bool swn_drop_g16(const swn_net_desc* d, int batch, long Tp);
+
 // BL6 class, mixed-precision mode, dropout as run.sh trains it (dilation_repeat == 1: the only hidden-state mask lands on the
 // last layer's output, which feeds nothing, so aux_drop is the one mask that acts - cswnv_shift1.py:194-195,211-217): the
 // forward work buffer of the fused path (csrc/swn_stack_bf16.hip: swn_bl6_drop_forward; read back by swn_bl6_bwd_stack).

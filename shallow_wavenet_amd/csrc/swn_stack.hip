@@ -314,7 +314,7 @@ int swn_train_layers_forward_drop(const SwnGeom& g, const SwnLayout& y, const fl
                                   hipStream_t st);
 // sample-rate in_x of every layer over the masked conditioning (csrc/swn_train.hip: generic time GEMM)
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
-                          int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16 = nullptr);
+                          int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16 = nullptr, bool g4 = false);
 // GEMM-stack geometries, mixed-precision mode: the dropout-mode forward on the bf16 time-major stack (csrc/swn_stack_bf16g.hip)
 int swn_bf16g_geom(const swn_net_desc* d, SwnGeom* g);
 size_t swn_bf16g_weight_bytes(const SwnGeom& g);
@@ -332,12 +332,18 @@ namespace {
 
 // does the dropout-mode forward of the mixed-precision mode run on the bf16 time-major GEMM stack?  (the geometry class of
 // csrc/swn_stack_bf16g.hip, its 32-bit operand offsets, a sequence long enough for the bf16-copy contractions)
-bool drop_g16(const swn_net_desc* d, int batch, long Tp) {
+bool drop_g16(const swn_net_desc* d, int batch, long Tp) { return swn_drop_g16(d, batch, Tp); }
+
+}  // namespace
+
+bool swn_drop_g16(const swn_net_desc* d, int batch, long Tp) {
     SwnGeom g;
     if (swn_bf16g_geom(d, &g) != SWN_OK || Tp < 256) return false;
     const size_t lstride = (size_t)batch * Tp * g.H;
     return (size_t)g.L * lstride * 2 < (1ull << 31) && (size_t)batch * Tp * (g.S > g.O1 ? g.S : g.O1) * 2 < (1ull << 31);
 }
+
+namespace {
 
 int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, const float* fe_work, const void* audio,
                  int batch, int n_frames, const float* drop_x, const float* const* drop_h, float* work, float* out,
@@ -396,11 +402,13 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
         } else
         hipLaunchKernelGGL(xm_fwd_kernel, dim3((Tx + 255) / 256, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
                            drop_x, xm, g.A0, swn_a0x(&g), n_frames, g.U, a.coff, Tx);
-        rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st, wx16);
+        // (the GEMM stack reads gx in the G4 layout, swn_geom.hpp; it needs the bf16-copy product kernel, i.e. wx16)
+        const bool g16 = !hs && swn_call_mode() == SWN_PRECISION_BF16 && drop_g16(d, batch, Tp) && wx16;
+        rc = swn_train_inx_forward(g, a.y, packed, xm, gx, batch, Tx, (int)Tp, st, wx16, g16);
         if (rc < 0) return rc;
         a.gx = gx;
     }
-    if (drop && !hs && swn_call_mode() == SWN_PRECISION_BF16 && drop_g16(d, batch, Tp)) {
+    if (drop && !hs && swn_call_mode() == SWN_PRECISION_BF16 && drop_g16(d, batch, Tp) && swn_drop_inx16(&g, Tp)) {
         // GEMM-stack geometries: input layer, gated layers (gate epilogue on the sample-rate in_x rows, a dropped level read through
         // its masked copy, pre-activations kept for the backward) and head on the bf16 time-major stack of the forward without
         // dropout; what the backward reads in fp32 (hidden states, relu(skip), relu(out_1)) is expanded from it.  Replaces one

@@ -46,8 +46,8 @@ struct GemmArgs {
     int H, l, seg, U, Tf, N, coff;
     const int* aidx; int Q;                        // softmax audio_in: class index of position t, or null
     int ntt, nmt;                                  // time tiles per utterance, row tiles (set by launch_gemm)
-    float* a_out;                                  // gate: where to keep the pre-activations (B, 2H, Tp) fp32 for the backward, or null
-    const float* gx; size_t o_bxr; int gx_rows;    // gate, dropout mode: sample-rate in_x products (B, gx_rows = L*2H, Tp) fp32 (row l*2H + o)
+    float* a_out;                                  // gate: where to keep the pre-activations (B, 2H, Tp) fp32 in the G4 layout for the backward, or null
+    const float* gx; size_t o_bxr; int gx_rows;    // gate, dropout mode: sample-rate in_x products (B, gx_rows = L*2H, Tp) fp32, G4 layout (row l*2H + o)
                                                    // instead of the hoisted cond, + the raw in_x bias (cswnv_shift1.py:194-198,269-278)
 };
 
@@ -160,12 +160,14 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
                 const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
                 if (ch >= H) continue;
                 float gz[4], gc[4];
-                if (a.gx) {
-                    const float* gr = a.gx + ((size_t)b * a.gx_rows + (size_t)l * H2 + ch) * a.Tp + t;     // 64-byte runs along t, as a_out
+                if (a.gx) {                                   // G4 layout (swn_geom.hpp): the lane's four channels are one 16-byte piece
+                    const float4 gz4 = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + ch, t));
+                    const float4 gc4 = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + H + ch, t));
+                    const float zz[4] = {gz4.x, gz4.y, gz4.z, gz4.w}, cc[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        gz[r] = gr[(size_t)r * a.Tp] + P[a.o_bxr + (size_t)l * H2 + ch + r];
-                        gc[r] = gr[(size_t)(H + r) * a.Tp] + P[a.o_bxr + (size_t)l * H2 + H + ch + r];
+                        gz[r] = zz[r] + P[a.o_bxr + (size_t)l * H2 + ch + r];
+                        gc[r] = cc[r] + P[a.o_bxr + (size_t)l * H2 + H + ch + r];
                     }
                 } else {
 #pragma unroll
@@ -191,10 +193,9 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
                 const uint2 hp2 = *reinterpret_cast<const uint2*>(a.hprev + ((size_t)b * a.Tp + t) * H + ch);
                 const float hp[4] = {bf2f((unsigned short)(hp2.x & 0xffff)), bf2f((unsigned short)(hp2.x >> 16)),
                                      bf2f((unsigned short)(hp2.y & 0xffff)), bf2f((unsigned short)(hp2.y >> 16))};
-                if (a.a_out) {     // training: the backward reads these instead of recomputing the dilated conv (64-byte runs along t)
-                    float* ao = a.a_out + ((size_t)b * H2 + ch) * a.Tp + t;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { ao[(size_t)r * a.Tp] = acc[2 * p][j][r]; ao[(size_t)(H + r) * a.Tp] = acc[2 * p + 1][j][r]; }
+                if (a.a_out) {     // training: the backward reads these instead of recomputing the dilated conv (G4 layout: 16-byte pieces)
+                    *reinterpret_cast<f32x4*>(a.a_out + swn_g4(H2, a.Tp, b, ch, t)) = acc[2 * p][j];
+                    *reinterpret_cast<f32x4*>(a.a_out + swn_g4(H2, a.Tp, b, H + ch, t)) = acc[2 * p + 1][j];
                 }
                 unsigned short hv[4];
 #pragma unroll

@@ -45,6 +45,7 @@ struct TimeGemm {
     const float* bias; int relu;                    // optional: v = acc + bias[m], then max(v, 0)  (forward 1x1 layers)
     int ksplit;                                     // > 1 (bf16 64x64 kernel only): the k range is cut into ksplit parts, one per
                                                     // workgroup, added atomically into a zeroed Y (frame-rate GEMMs: few tiles, long k)
+    int y_g4;                                       // time_gemm_b16_kernel only: Y (B, M, T) is stored in the G4 layout (swn_geom.hpp), plain store
     // optional bf16 operands (time_gemm_b16_kernel: data gradients of the mixed-precision chain)
     const unsigned short* A16; long a16_sm, a16_stap;   // A(m, tap, c) = A16[tap * a16_stap + m * a16_sm + c]  (c contiguous)
     const unsigned short* X16; long x16_sb, x16_sc, x16_odd;   // X[b][c][t] = X16[b * x16_sb + c * x16_sc + t], and x16_odd elements on a
@@ -399,6 +400,8 @@ __global__ __launch_bounds__(256) void time_gemm_bf16t_kernel(const TimeGemm g) 
 // 128-row tiles left the second row tile half empty - a quarter of the MFMAs and of the A traffic on zeros; 96-row tiles fit.
 typedef short swn_s16x4 __attribute__((ext_vector_type(4)));
 typedef short swn_s16x8 __attribute__((ext_vector_type(8)));
+// (The 128-row form needs 183 registers and spills 15 under the three-workgroup bound; bound to two workgroups it measured slower on
+// the long-k data gradient of in_x - 530 against 475 us - and the same on the output-bound forward product.)
 template <int MT>
 __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g) {
     constexpr int RM = 32 * MT;
@@ -502,6 +505,16 @@ __global__ __launch_bounds__(256, 3) void time_gemm_b16_kernel(const TimeGemm g)
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int e = 0; e < 4; ++e) mrow[4 * i + e] = m0 + 16 * MT * wm + 16 * i + 4 * kq + e;
+    if (g.y_g4) {                                              // a lane's four rows of a position: one 16-byte piece (M % 4 == 0)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int t = t0 + 64 * wn + 16 * j + rc;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                if (t < g.T && mrow[4 * i] < g.M) *reinterpret_cast<swn_f32x4*>(g.Y + swn_g4(g.M, g.T, b, mrow[4 * i], t)) = acc[i][j];
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v[4 * MT];
@@ -944,25 +957,39 @@ struct GateBwd {
                                                // skip_da32: both GEMMs read the copies, the fp32 da is not stored
     unsigned short* h16; long h16_odd;         // optional: the layer's (masked) input as two bf16 copies like da16's (rows of
                                                // da16_pitch elements): the weight gradient's Q operand (ReduceGemm::Q16)
+    int g4;                                    // a_in and gx are in the G4 layout (swn_geom.hpp): the GEMM stack wrote / read them
     unsigned short* dgx16; long dgx16_sb;      // optional (swn_drop_inx16): d gx as bf16 rows of da16_pitch elements INSTEAD of the
                                                // fp32 dgx - the operand of the two merged in_x contractions behind the layer loop
 };
 
-template <int KIND>
-__global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
+// One (position, channel) of the gate backward.  G4: the pre-activations (and, dropout mode, the in_x rows) arrive as values - the
+// caller read its four channels' 16-byte pieces of the G4 layout (swn_geom.hpp) - instead of being read from (B, R, Tp) tensors.
+struct GbIn { float im, hprev, dh, dhl; };     // per (position, channel): input mask, (masked) layer input, d h_{l+1}, d h_l so far
+__device__ __forceinline__ GbIn gate_bwd_in(const GateBwd& a, const int b, const int t, const int o) {
+    const int H = a.g.H;
+    const size_t hb = ((size_t)b * (a.g.L + 1)) * H * a.Tp;
+    GbIn r;
+    r.im = a.in_mul ? a.in_mul[((size_t)b * H + o) * a.Tp + t] : 1.f;
+    r.hprev = a.hs[hb + ((size_t)a.l * H + o) * a.Tp + t] * r.im;
+    r.dh = a.dhs[hb + ((size_t)(a.l + 1) * H + o) * a.Tp + t];
+    r.dhl = a.dhs[hb + ((size_t)a.l * H + o) * a.Tp + t];
+    return r;
+}
+template <int KIND, bool G4>
+__device__ __forceinline__ void gate_bwd_one(const GateBwd& a, const int b, const int t, const int o, const GbIn in, const float pz,
+                                             const float pc, const float xz, const float xc) {
     const SwnGeom& g = a.g;
-    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
-    if (t >= a.Tp) return;
     const int H = g.H, H2 = 2 * g.H, l = a.l, seg = g.seg;
     const float* P = a.P;
     const size_t hb = ((size_t)b * (g.L + 1)) * H * a.Tp;
-    const float im = a.in_mul ? a.in_mul[((size_t)b * H + o) * a.Tp + t] : 1.f;
-    const float hprev = a.hs[hb + ((size_t)l * H + o) * a.Tp + t] * im;
-    const float dh = a.dhs[hb + ((size_t)(l + 1) * H + o) * a.Tp + t];
+    const float im = in.im, hprev = in.hprev, dh = in.dh;
     float* az = a.a_da + ((size_t)b * H2 + o) * a.Tp + t;
     float* ac = a.a_da + ((size_t)b * H2 + H + o) * a.Tp + t;
     float gz, gc;
-    if (a.gx) {
+    if (G4 && a.gx) {
+        gz = xz + P[a.y.bxr + (size_t)l * H2 + o];
+        gc = xc + P[a.y.bxr + (size_t)l * H2 + H + o];
+    } else if (a.gx) {
         const float* gr = a.gx + (((size_t)b * g.L + l) * H2) * a.Tp + t;
         gz = gr[(size_t)o * a.Tp] + P[a.y.bxr + (size_t)l * H2 + o];
         gc = gr[(size_t)(H + o) * a.Tp] + P[a.y.bxr + (size_t)l * H2 + H + o];
@@ -985,8 +1012,8 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
         gz += wa[o]; gc += wa[H + o];
     }
     const float* ain = a.a_in ? a.a_in : a.a_da;
-    const float sz = ain[((size_t)b * H2 + o) * a.Tp + t] + P[a.y.bd + (size_t)l * H2 + o];
-    const float sc = ain[((size_t)b * H2 + H + o) * a.Tp + t] + P[a.y.bd + (size_t)l * H2 + H + o];
+    const float sz = (G4 ? pz : ain[((size_t)b * H2 + o) * a.Tp + t]) + P[a.y.bd + (size_t)l * H2 + o];
+    const float sc = (G4 ? pc : ain[((size_t)b * H2 + H + o) * a.Tp + t]) + P[a.y.bd + (size_t)l * H2 + H + o];
     const float z = sigm(gz * sz), c = tanhf(gc * sc);
     const float dz = dh * (hprev - c) * z * (1.f - z);      // d/d(gz*sz)
     const float dc = dh * (1.f - z) * (1.f - c * c);        // d/d(gc*sc)
@@ -1015,7 +1042,36 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
         atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + o, dz * sz);
         atomicAdd(a.gwxa + ((size_t)l * g.Q + idx) * H2 + H + o, dc * sc);
     }
-    a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] += dh * z * im;   // highway path (through the input's dropout mask)
+    a.dhs[hb + ((size_t)l * H + o) * a.Tp + t] = in.dhl + dh * z * im;   // highway path (through the input's dropout mask)
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const GateBwd a) {
+    const int t = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y, b = blockIdx.z;
+    if (t >= a.Tp) return;
+    gate_bwd_one<KIND, false>(a, b, t, o, gate_bwd_in(a, b, t, o), 0.f, 0.f, 0.f, 0.f);
+}
+
+// the same with the kept pre-activations (and the in_x rows of the dropout mode) in the G4 layout: a thread takes FOUR channels of
+// its position, whose pre-activations are one 16-byte piece (read channel by channel they were strided 4-byte loads: 216 -> 278 us
+// per layer at the run.sh geometry); everything else is read and written per channel, lanes along t, as above.  H % 4 == 0.
+template <int KIND>
+__global__ __launch_bounds__(256) void gate_bwd_g4_kernel(const GateBwd a) {
+    const int t = blockIdx.x * 256 + threadIdx.x, o0 = 4 * blockIdx.y, b = blockIdx.z;
+    if (t >= a.Tp) return;
+    const int H = a.g.H, H2 = 2 * a.g.H;
+    const swn_f32x4 pz = *reinterpret_cast<const swn_f32x4*>(a.a_in + swn_g4(H2, a.Tp, b, o0, t));
+    const swn_f32x4 pc = *reinterpret_cast<const swn_f32x4*>(a.a_in + swn_g4(H2, a.Tp, b, H + o0, t));
+    swn_f32x4 xz = {0.f, 0.f, 0.f, 0.f}, xc = {0.f, 0.f, 0.f, 0.f};
+    if (a.gx) {
+        xz = *reinterpret_cast<const swn_f32x4*>(a.gx + swn_g4(a.g.L * H2, a.Tp, b, a.l * H2 + o0, t));
+        xc = *reinterpret_cast<const swn_f32x4*>(a.gx + swn_g4(a.g.L * H2, a.Tp, b, a.l * H2 + H + o0, t));
+    }
+    GbIn in[4];                                                // every load of the four channels ahead of the first store (they may alias)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) in[r] = gate_bwd_in(a, b, t, o0 + r);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) gate_bwd_one<KIND, true>(a, b, t, o0 + r, in[r], pz[r], pc[r], xz[r], xc[r]);
 }
 
 // zeroes `n` floats at the start of each of gridDim.y rows `stride` floats apart
@@ -1644,7 +1700,7 @@ __global__ __launch_bounds__(256) void wx16_kernel(const float* __restrict__ wx,
 }  // namespace
 
 int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* packed, const float* xm, float* gx,
-                          int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16) {
+                          int B, int Tx, int Tp, hipStream_t st, unsigned short* wx16, bool g4) {
     const int H2 = 2 * g.H;
     if (g.seg == 1) {                 // one launch over the L * 2H rows of the [N][A0p] matrix (row n = l*2H + o): gx is (B, L*2H, Tp)
         const int A0x = swn_a0x(&g);
@@ -1656,6 +1712,7 @@ int swn_train_inx_forward(const SwnGeom& g, const SwnLayout& y, const float* pac
             const long px = swn_pitch16(Tx);
             t.A16 = wx16; t.a16_sm = A0x; t.a16_stap = 0;
             t.X16 = reinterpret_cast<const unsigned short*>(xm); t.x16_sb = (long)A0x * px; t.x16_sc = px; t.x16_odd = 0;
+            t.y_g4 = g4 ? 1 : 0;
         }
         launch_time(t, B, st);
         return SWN_OK;
@@ -1828,6 +1885,8 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
     unsigned short* wxt16 = inx16 ? reinterpret_cast<unsigned short*>(dgx_all + r64((size_t)B * L * H2 * Tp)) : nullptr;
     ga.B = B; ga.Tf = n_frames; ga.Tp = Tp; ga.coff = coff;
     ga.gx = drop ? gx : nullptr;
+    // the GEMM stack keeps its pre-activations - and, when it ran the dropout-mode forward, read its in_x rows - in the G4 layout
+    ga.g4 = (a_keep || (drop && !drop_fused && !hs_opt && mode_bf16() && swn_drop_g16(d, B, Tp) && swn_drop_inx16(&g, Tp))) ? 1 : 0;
     ga.gwxa = g.audio_in ? gpacked + y.wxa : nullptr;
     // ---- layers, last to first
     if (hs_bf16) {
@@ -1861,7 +1920,11 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
                           H2, g.K, H, Tp, 1, g.K - 1, g.dil[l], 0};
             launch_time(t, B, st);
         }
-        {
+        if (ga.g4 && ga.a_in) {
+            dim3 grid((Tp + 255) / 256, H / 4, B);
+            if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(gate_bwd_g4_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, ga);
+            else hipLaunchKernelGGL(gate_bwd_g4_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, ga);
+        } else {
             dim3 grid((Tp + 255) / 256, H, B);
             if (g.kind == SWN_KIND_LAPLACE) hipLaunchKernelGGL(gate_bwd_kernel<SWN_KIND_LAPLACE>, grid, dim3(256), 0, st, ga);
             else hipLaunchKernelGGL(gate_bwd_kernel<SWN_KIND_SOFTMAX>, grid, dim3(256), 0, st, ga);
