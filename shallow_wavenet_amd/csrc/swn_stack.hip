@@ -291,17 +291,37 @@ __global__ __launch_bounds__(256) void xm_fwd_kernel(const float* __restrict__ C
     xm[ox] = drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]);
 }
 
-// the same as bf16 rows of `pitch` elements (swn_drop_inx16: operand of the bf16-copy contraction kernels, csrc/swn_train.hip)
+// the same as bf16 rows of `pitch` elements (swn_drop_inx16: operand of the bf16-copy contraction kernels, csrc/swn_train.hip).
+// A thread takes eight consecutive positions: two 16-byte mask loads, one 16-byte store (one element per thread - 4-byte loads,
+// 2-byte stores - ran at 2.1 TB/s: 187 us for the 257 MB mask at the run.sh geometry).
 __global__ __launch_bounds__(256) void xm_fwd16_kernel(const float* __restrict__ C, const float* __restrict__ P, size_t wup, size_t bup,
                                                        const float* __restrict__ drop_x, unsigned short* __restrict__ xm16,
                                                        int A0, int A0x, int Tf, int U, int coff, int Tx, long pitch) {
-    const int u = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, b = blockIdx.z;
-    if (u >= Tx) return;
-    unsigned short* dst = xm16 + ((size_t)b * A0x + c) * pitch + u;
-    if (c >= A0) { *dst = 0; return; }
-    const int tt = u + coff, f = tt / U, j = tt - f * U;
-    const size_t o = ((size_t)b * A0 + c) * Tx + u;
-    *dst = (unsigned short)(swn_pack_bf16(drop_x[o] * fmaf(C[((size_t)b * A0 + c) * Tf + f], P[wup + j], P[bup]), 0.f) & 0xffffu);
+    const int u0 = (blockIdx.x * 256 + threadIdx.x) * 8, c = blockIdx.y, b = blockIdx.z;
+    if (u0 >= Tx) return;
+    unsigned short* dst = xm16 + ((size_t)b * A0x + c) * pitch + u0;          // pitch % 32 == 0: 16-byte aligned
+    unsigned w[4] = {0u, 0u, 0u, 0u};
+    if (c < A0) {
+        // (a view that ends with the mask tensor: the last row's final piece may reach past it and must read zeros, not memory)
+        const size_t left = ((size_t)(gridDim.z - b) * A0 - c) * Tx * sizeof(float);
+        const __amdgpu_buffer_rsrc_t rM = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(drop_x + ((size_t)b * A0 + c) * Tx), 0,
+                                                                            left < 0x7fffffffu ? (unsigned)left : 0x7fffffffu, 0x00020000);
+        const swn_fl4 m0 = bld4(rM, (unsigned)(u0 * 4)), m1 = bld4(rM, u0 + 4 < Tx ? (unsigned)((u0 + 4) * 4) : SWN_OOB);
+        const float m[8] = {m0.x, m0.y, m0.z, m0.w, m1.x, m1.y, m1.z, m1.w};
+        const float* Cr = C + ((size_t)b * A0 + c) * Tf;
+        const float bu = P[bup];
+        int f = (u0 + coff) / U, j = u0 + coff - f * U;
+        float cf = Cr[f];
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            v[e] = u0 + e < Tx ? m[e] * fmaf(cf, P[wup + j], bu) : 0.f;
+            if (++j == U) { j = 0; ++f; cf = Cr[f < Tf ? f : Tf - 1]; }
+        }
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w[d] = swn_pack_bf16(v[2 * d], v[2 * d + 1]);
+    }
+    *reinterpret_cast<uint4*>(dst) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 }  // namespace
@@ -397,7 +417,7 @@ int forward_impl(const swn_net_desc* d, const float* packed, const float* cond, 
             // end of the work buffer
             wx16 = reinterpret_cast<unsigned short*>(gx + r64((size_t)batch * g.L * 2 * g.H * Tp) +
                                                      (size_t)g.L * r64((size_t)batch * 2 * g.H * Tp) + r64((size_t)batch * g.H * Tp));
-            hipLaunchKernelGGL(xm_fwd16_kernel, dim3((Tx + 255) / 256, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
+            hipLaunchKernelGGL(xm_fwd16_kernel, dim3((Tx + 2047) / 2048, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
                                drop_x, reinterpret_cast<unsigned short*>(xm), g.A0, swn_a0x(&g), n_frames, g.U, a.coff, Tx, swn_pitch16(Tx));
         } else
         hipLaunchKernelGGL(xm_fwd_kernel, dim3((Tx + 255) / 256, swn_a0x(&g), batch), dim3(256), 0, st, C, packed, a.y.wup, a.y.bup,
