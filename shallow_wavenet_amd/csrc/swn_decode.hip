@@ -320,6 +320,11 @@ extern "C" int swn_decode_bl6_try(const swn_net_desc* d, const float* packed, co
                                   int batch, int n_frames, int n_steps, const SwnNoise* nz,
                                   const void* forced, const void* seed, void* out, float* heads, void* stream);
 
+// defined in swn_decode_bl6w.hip: the wave-specialised form for the single-sample Laplace nets of that class
+extern "C" int swn_decode_bl6w_try(const swn_net_desc* d, const float* packed, const float* cond,
+                                   int batch, int n_frames, int n_steps, const SwnNoise* nz,
+                                   const void* forced, const void* seed, void* out, float* heads, void* stream);
+
 // defined in swn_decode_stepped.hip
 extern "C" size_t swn_decode_stepped_state_floats(const swn_net_desc* d, int batch);
 extern "C" int swn_decode_stepped(const swn_net_desc* d, const float* packed, const float* cond, int batch, int n_frames,
@@ -351,9 +356,13 @@ extern "C" int swn_decode(const swn_net_desc* d, const float* packed, const floa
     const void* seed = io->seed_dev;
     hipStream_t st = (hipStream_t)stream_;
     (void)hipGetLastError();   // drop stale errors of earlier runtime calls
-    if (variant == 0 || variant == 2) {
+    if (variant == 0 || variant == 2) {        // BL6 class: the wave-specialised kernel where it applies, else the symmetric one
+        rc = swn_decode_bl6w_try(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, out, heads, stream_);
+        if (rc != SWN_E_UNSUPPORTED) return rc;
+    }
+    if (variant == 0 || variant == 2 || variant == 6) {     // 6 = the symmetric BL6 kernel, whatever the net (A/B and parity runs)
         rc = swn_decode_bl6_try(d, packed, cond, batch, n_frames, n_steps, &nz, forced, seed, out, heads, stream_);
-        if (rc != SWN_E_UNSUPPORTED || variant == 2) return rc;
+        if (rc != SWN_E_UNSUPPORTED || variant != 0) return rc;
     }
     if (!state) return SWN_E_BADARG;
     // large geometries (REF6: MBs of weights per step) run one launch per phase over many CUs
