@@ -136,7 +136,9 @@ int    swn_frontend(const swn_net_desc* d, const float* packed_dev, const float*
  *   state_dev   swn_decode_state_floats() scratch (history rings; zeroed by the call)
  *   out_dev     laplace: (B, n_steps*seg) fp32 ; softmax: (B, n_steps) int32
  *   heads_dev   optional (B, n_steps, n_out) raw out_2 outputs at each step (may be NULL)
- *   variant     0 = auto, 1 = generic persistent kernel, 2 = register/LDS-resident BL6-class kernel,
+ *   variant     0 = auto, 1 = generic persistent kernel, 2 = register/LDS-resident BL6-class kernels (the wave-specialised
+ *                   form for the single-sample Laplace nets, the symmetric form for the others), 6 = the symmetric BL6-class
+ *                   kernel whatever the net (A/B and parity runs),
  *               3 = stepped multi-launch decode for large geometries (REF6: what auto picks there)
  *                   (from 24 utterances on in tiles of 8 channel pairs x 8 utterances that fetch a pair's weight rows once per
  *                   tile and stage the utterances' activations in LDS).

@@ -31,8 +31,10 @@ def _net(cfg, d):
 
 
 def _variants(cfg):
-    """1 generic persistent, 3 stepped multi-launch, 0 auto (BL6 fast kernel / stepped for REF6)"""
-    return [1, 3, 0]
+    """1 generic persistent, 3 stepped multi-launch, 0 auto (BL6 fast kernels / stepped for REF6); BL6-class nets also 6 = the
+    symmetric BL6 kernel (auto takes the wave-specialised one for the single-sample Laplace nets)"""
+    bl6 = cfg.H == 64 and cfg.kernel_size == 2 and cfg.dilation_depth == 6 and cfg.dilation_repeat == 1
+    return [1, 3, 0] + ([6] if bl6 else [])
 
 
 @pytest.mark.parametrize("name", LAP)

@@ -27,10 +27,11 @@ def _net(cfg, seed=7, flavor="trained"):
 
 
 @pytest.mark.parametrize("cfgname,variants", [("tiny_s1l0", (1, 3)), ("tiny_s5l4", (1, 3)), ("tiny_s2l4", (1, 3)),
-                                              ("bl6_s1l0", (2, 1)), ("bl6_s5l4", (2, 1))])
+                                              ("bl6_s1l0", (2, 6, 1)), ("bl6_s1l4", (2, 6, 1)), ("bl6_s5l4", (2, 1))])
 def test_laplace_device_noise_replays_in_the_oracle(gpu_ok, cfgname, variants):
     cfg = {"tiny_s1l0": C.tiny("laplace", 1, 0), "tiny_s5l4": C.tiny("laplace", 5, 4), "tiny_s2l4": C.tiny("laplace", 2, 4),
-           "bl6_s1l0": C.bl6_laplace(1, 0), "bl6_s5l4": C.bl6_laplace(5, 4)}[cfgname]
+           "bl6_s1l0": C.bl6_laplace(1, 0), "bl6_s1l4": C.bl6_laplace(1, 4), "bl6_s5l4": C.bl6_laplace(5, 4)}[cfgname]
+    # (BL6 single-sample nets: 2 = the wave-specialised kernel in its extended instantiation, 6 = the symmetric kernel)
     net, P = _net(cfg)
     B, Tf = 3, 4
     n_steps = Tf * cfg.U // cfg.seg

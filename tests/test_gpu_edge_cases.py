@@ -87,6 +87,35 @@ def test_variants_agree_on_a_ragged_batch(gpu_ok):
     assert float((g - f).abs().max()) <= 1e-5
 
 
+@pytest.mark.parametrize("lpc", [0, 4])
+def test_wave_specialised_decode_against_the_oracle_and_the_symmetric_kernel(gpu_ok, lpc):
+    """single-sample Laplace nets of the BL6 class decode on csrc/swn_decode_bl6w.hip (variant 0 / 2): against the CPU oracle
+    (1e-5, host-drawn noise, three utterances over a frame boundary and a ragged tail), against the symmetric kernel (variant 6),
+    teacher-forced inputs and the heads included; lpc = 4 has no reference-generated BL6 fixture of its own"""
+    from oracle import cpu_ref
+    cfg = C.bl6_laplace(1, lpc)
+    sd = synth_state_dict(cfg, seed=11, flavor="trained")
+    net, P = HipNet.from_state_dict(cfg, sd, "cuda:0"), cpu_ref.as_params(sd)
+    B, Tf = 3, 3
+    n = Tf * cfg.U
+    aux = synth_aux(cfg, B, Tf, seed=5)
+    aux[2, :, 2:] = 0
+    aux = torch.from_numpy(aux)
+    g = torch.Generator().manual_seed(9)
+    noise = cpu_ref.laplace_noise(cfg, n, B, generator=g)                     # (n, B, 1)
+    want = cpu_ref.laplace_generate(cfg, P, aux, [n, n, n - 37], noise)
+    nz = torch.from_numpy(noise).permute(1, 0, 2).contiguous()
+    new, hn = net.decode(aux, n, nz, want_heads=True, variant=2)
+    old, ho = net.decode(aux, n, nz, want_heads=True, variant=6)
+    for b, m in enumerate((n, n, n - 37)):
+        assert np.abs(new[b, :m].cpu().numpy() - want[b][:m]).max() <= 1e-5, (lpc, b)
+    assert float((new - old).abs().max()) <= 1e-5 and float((hn - ho).abs().max()) <= 1e-5
+    forced = torch.from_numpy(np.stack([np.resize(w, n) for w in want]).astype(np.float32))
+    fn, hfn = net.decode(aux, n, nz, forced=forced, want_heads=True, variant=2)
+    fo, hfo = net.decode(aux, n, nz, forced=forced, want_heads=True, variant=6)
+    assert float((fn - fo).abs().max()) <= 1e-5 and float((hfn - hfo).abs().max()) <= 1e-5
+
+
 def test_forward_minimal_length(gpu_ok):
     cfg = C.tiny("laplace", 2, 4)
     net = _net(cfg)
