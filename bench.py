@@ -101,11 +101,11 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s
 MFMA_BF16_TFLOPS = 2500.0        # dense bf16 MFMA peak
 MFMA_FP32_TFLOPS = 157.0         # fp32 matrix peak (exact-fp32 MFMA parity kernels)
 
-# HBM bytes per decode launch from rocprofv3 PMC passes (profiles/r01_pmc_hbm_traffic.csv), keyed by
+# HBM bytes per decode launch from rocprofv3 PMC passes (profiles/r03_pmc_headline.csv: the wave-specialised kernel), keyed by
 # (utterances per GPU, frames): 2 x FETCH_SIZE (gfx950 counts wide coalesced reads at half their bytes,
 # MI355X_MICROARCH.md section HBM) + WRITE_SIZE, in bytes.  Measured offline: counters cannot be read
 # from inside this process.  Other shapes report null.
-PMC_TRAFFIC_BYTES = {(1, 600): int((2 * 1369.8 + 257.8) * 1024)}
+PMC_TRAFFIC_BYTES = {(1, 600): int((2 * 1378.2 + 257.8) * 1024)}
 
 
 def algorithmic_bytes_per_position(cfg: C.NetConfig, batch: int) -> float:
@@ -434,7 +434,7 @@ def cfg5_leg(dev, rank: int, world: int, reps: int = 2):
             "us_per_step": round(elapsed * 1e6 / positions, 3),
             "value": round(world * B * n_steps / elapsed, 1), "unit": "samples/s (all ranks)",
             "real_time_factor_per_utterance": round(n_steps / elapsed / 22050.0, 2),
-            "roofline": _hbm(bpp * positions, elapsed * 1e3, kernel="decode_bl6_kernel (one workgroup per utterance)",
+            "roofline": _hbm(bpp * positions, elapsed * 1e3, kernel="decode_bl6w_kernel (one workgroup per utterance)",
                              algorithmic_bytes_per_position=round(bpp, 1), positions_per_launch=positions)}
 
 
@@ -452,7 +452,7 @@ def run_legs(dev, quick: bool = False):
 
     bl6 = C.bl6_laplace(1, 0)
     add("cfg2_caller", decode_leg, "cfg2: CSWNV BL6 seg=1 lpc=0, 22.05 kHz, 1 utterance x Tf=600, batch_fast_generate as called",
-        bl6, dev, 1, 600, 22050, 1, "decode_bl6_kernel", caller=True)
+        bl6, dev, 1, 600, 22050, 1, "decode_bl6w_kernel", caller=True)
     add("cfg1", decode_leg, "cfg1: DSWNV BL6 softmax mu-law 256 (H=64, S=256, K=2), 16 kHz, 1 utterance x Tf=600 (48 000 steps)",
         C.bl6_softmax(), dev, 1, 600, 16000, 2, "decode_bl6_kernel<softmax>", caller=True)
     add("cfg3", decode_leg, "cfg3: CSWNV BL6 seg=5 lpc=4 (multi-sample output + LP), 22.05 kHz, 1 utterance x Tf=600 (13 200 steps)",
@@ -510,6 +510,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="headline only (profiling runs)")
     ap.add_argument("--quick-legs", action="store_true", help="decode legs only")
+    ap.add_argument("--no-cfg5", action="store_true", help="skip the 64-utterance leg too (counter passes over the headline launch alone)")
     ap.add_argument("--plan-only", action="store_true",
                     help="no GPU work: join the process group (gloo), count the ranks, print the line's skeleton "
                          "(what the CPU tests drive)")
@@ -601,9 +602,9 @@ def main():
         "us_per_sample_step": round(kern_ms * 1e3 / positions, 3),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": PMC_TRAFFIC_BYTES.get((B, Tf)),
-                     "traffic_src": "constant from an offline rocprofv3 --pmc pass (profiles/r02_pmc_hbm_traffic_decode.csv), "
+                     "traffic_src": "constant from an offline rocprofv3 --pmc pass (profiles/r03_pmc_headline.csv), "
                                     "not read in this process",
-                     "kernel": "decode_bl6_kernel", "kernel_ms": round(kern_ms, 3),
+                     "kernel": "decode_bl6w_kernel", "kernel_ms": round(kern_ms, 3),
                      "algorithmic_bytes_per_position": round(bytes_pos, 1), "positions_per_launch": positions,
                      "note": "latency-bound sequential chain; working set on-chip"},
         "legs_doc": "profiles/LEGS.md (units, kernels, pricing per leg; frac_design = priced on the design's own stream bytes)",
@@ -612,10 +613,11 @@ def main():
         line["rehearsal"] = f"{world} ranks share {n_dev} GPU(s) over gloo: the N > 1 code path, not a scaling measurement"
     detail = {}
     # cfg5 (64 utterances per rank) on every rank at every N: the scaling curve's second line
-    try:
-        detail["cfg5"] = cfg5_leg(dev, rank, world)
-    except Exception as e:                                          # noqa: BLE001
-        detail["cfg5"] = {"error": f"{type(e).__name__}: {e}"}
+    if not args.no_cfg5:
+        try:
+            detail["cfg5"] = cfg5_leg(dev, rank, world)
+        except Exception as e:                                      # noqa: BLE001
+            detail["cfg5"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1:
         # auxiliary measurements: a failure there must not cost the headline line
         if not args.no_legs:

@@ -11,7 +11,7 @@ echo "bench trace done"
 fi
 # (2) headline decode kernel: HBM traffic counters, separate passes
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_decode_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-legs --no-cpu-baseline --detail "" > $O/pmc_decode_$c.log 2>&1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_decode_$c -o p -- python3 $R/bench.py --steps 2 --warmup 1 --no-legs --no-cfg5 --no-cpu-baseline --detail "" > $O/pmc_decode_$c.log 2>&1
   echo "pmc decode $c done"
 done
 # (3) bf16 forward at cfg4's own size and at 8x the batch: kernel times, then HBM traffic of the fused stack kernel
