@@ -149,6 +149,8 @@ __device__ __forceinline__ void layer_a(float* lds, const float (&w)[2][16], con
         if (fabsf(v) > 9.02f && p == 1) {
             res = copysignf(1.f, v);                                       // tanh saturated in fp32
         } else {
+            // (plain v_exp_f32 / v_rcp_f32 without the corrections - nine instructions fewer on the chain - measured the same step
+            //  time: the phase waits for both groups, not for this arithmetic)
             const float e = exp_c(p == 0 ? -v : -2.f * fabsf(v));
             const float r = rcp_c(1.f + e);
             res = p == 0 ? r : copysignf((1.f - e) * r, v);                // z | tanh
