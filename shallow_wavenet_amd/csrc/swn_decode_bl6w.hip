@@ -10,9 +10,12 @@
 //   * group A (waves 0-3, one per SIMD) owns the chain: per layer the CURRENT-tap half (128 rows x 64 inputs: thread (o, p) two
 //     rows x 16 inputs, reduced over 4 lanes), the gate epilogue, the hand-off through LDS;
 //   * group B (waves 4-7, the other wave of every SIMD) works one step AHEAD and off the chain: the OLDER-tap halves (+ bias) of
-//     all six layers for step t + 1, left in LDS, and the whole out_skip accumulation of step t (slice l in the phase after layer l);
-//   * both groups keep their halves of all six matrices in registers (192 per thread: no layer lives in LDS any more), the out_1
-//     matrix is LDS-resident whole (the 64 KB the sixth layer used to take), only out_skip streams from L2.
+//     all six layers for step t + 1, left in LDS (formed where group B has room: one in the first layer phase, three beside group
+//     A's out_1, two beside wave 0's tail), and the whole out_skip accumulation of step t (slice l in the phase after layer l);
+//   * group A keeps its halves of all six matrices in registers (192 per thread), group B five of them (160) and the sixth in LDS
+//     (it also holds a slice of out_skip weights in flight); the out_1 matrix is LDS-resident whole (the 64 KB the sixth layer of
+//     the symmetric kernel took), only out_skip streams from L2;
+//   * out_1 is group A's alone (two rows per thread), out_2 + sampling + the next input layer wave 0's, as before.
 // Same arithmetic per element as the symmetric kernel up to the order of the partial sums (1e-7 relative); same noise, seed,
 // forced-input and heads interface (swn_decode_bl6.hip: classic = host-drawn noise, zero seed; extended = in-kernel generator,
 // noise dump, caller's seed waveform).  9 barriers per step.  cswnv_shift1.py:281-430.
