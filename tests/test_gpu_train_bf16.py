@@ -300,3 +300,36 @@ def test_kept_preactivations_match_the_recompute(gpu_ok):
         assert torch.equal(got[True][0], got[False][0])
         a, b = got[True][1].double(), got[False][1].double()
         assert float((a - b).norm()) <= 2e-3 * float(b.norm()), (cfg.kind, float((a - b).norm()), float(b.norm()))
+
+
+def test_gemm_stack_dropout_step_softmax_audio_in(gpu_ok):
+    """the dropout-mode forward of the mixed-precision mode on the bf16 GEMM stack (swn_drop_g16: H % 64 == 0 nets) with everything
+    the run.sh fixtures do not switch on at once: a softmax net with the one-hot audio columns of in_x (`audio_in_flag`), a mask
+    between layers (dilation_repeat 2), an odd sequence length (the G4 layout's ragged last block, the bf16 rows' ragged last
+    octet), three utterances.  Same host-drawn masks in both arithmetic modes; logits within 2e-2 of scale, every gradient
+    within 1e-1 of the fp32 mode's (the softmax tolerance of the teacher-forced fixtures)."""
+    cfg = C.NetConfig(kind="softmax", n_aux=10, hid_chn=64, skip_chn=64, dilation_depth=2, dilation_repeat=2, kernel_size=3,
+                      upsampling_factor=37, n_quantize=64, wav_conv_flag=False, audio_in_flag=True)
+    B, Tf = 3, 9                                                      # T = 333, Tp = 332 positions (>= 256: the bf16-copy kernels)
+    m = md.DSWNV(**cfg.ctor_kwargs(), do_prob=0.5)
+    m.dropout_source = "host"
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=5, flavor="trained").items()})
+    m.cuda().train()
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    T = Tf * cfg.U
+    g = torch.Generator().manual_seed(4)
+    idx = torch.randint(0, cfg.n_quantize, (B, T - 1), generator=g).cuda()
+    tgt = torch.randint(0, cfg.n_quantize, (B, T - 1), generator=g).cuda()
+    out, fwd = {}, {}
+    for mode in ("fp32", "bf16"):
+        for p in m.parameters():
+            p.grad = None
+        with train_precision(mode):
+            torch.manual_seed(13)
+            logits = m(md.OneHot(idx, cfg.n_quantize).transpose(1, 2), aux, do=True)
+            fwd[mode] = logits.detach().clone()
+            torch.nn.CrossEntropyLoss()(logits.reshape(-1, cfg.n_quantize), tgt.reshape(-1)).backward()
+        out[mode] = _grads(m)
+    assert float((fwd["bf16"] - fwd["fp32"]).abs().max()) <= 2e-2 * max(1.0, float(fwd["fp32"].abs().max()))
+    assert float((fwd["bf16"] - fwd["fp32"]).abs().max()) > 0, "the bf16 forward did not engage"
+    _close("g16_softmax_audio_in", out["bf16"], {k: v.astype(np.float64) for k, v in out["fp32"].items()}, tol=1e-1, floor=5e-5)
