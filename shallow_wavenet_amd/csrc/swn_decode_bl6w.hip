@@ -274,6 +274,8 @@ __device__ __forceinline__ void decode_body(const W6Args& a, float* lds) {
     constexpr bool grpA = GA;
     const int tid = threadIdx.x, b = blockIdx.x;
     __builtin_assume(GA ? tid < NG : tid >= NG);              // group B compiles none of wave 0's and wave 1's side jobs (head, noise, input layer)
+    // (a raised s_setprio for group A - the chain first at the SIMD's issue arbitration - measured no gain: 283.6 / 278.8 / 282.9 k
+    //  samples/s at priority 0 / 1 / 3)
     const int tg = tid & (NG - 1);                            // index inside the group
     const float* __restrict__ P = a.P;
     const int U = a.U;
