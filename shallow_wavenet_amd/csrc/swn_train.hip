@@ -1116,7 +1116,9 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     const int H2 = 2 * g.H, l = a.l, seg = g.seg, U = g.U;
     const int ncol = U + seg - 1;
     wus[tid] = tid < U ? a.P[a.y.wup + tid] : 0.f;
-    const __amdgpu_buffer_rsrc_t rD = rsrc_of(a.dgx + (size_t)b * a.dgx_sb);
+    // (mixed-precision chain: gate_bwd left d gx as bf16 rows of da16_pitch elements - half the bytes of this kernel's one big read)
+    const bool d16 = a.dgx16 != nullptr;
+    const __amdgpu_buffer_rsrc_t rD = d16 ? rsrc_of(a.dgx16 + (size_t)b * a.dgx16_sb) : rsrc_of(a.dgx + (size_t)b * a.dgx_sb);
     const int o2 = blockIdx.x * 64 + tid;
     float bsum = 0.f, wacc[2] = {0.f, 0.f};      // tid < 64: row sum ; tid >= 64: taps tid - 64 and tid + 128
     const int f1 = (blockIdx.y + 1) * FR < a.Tf ? (blockIdx.y + 1) * FR : a.Tf;
@@ -1131,6 +1133,22 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
         for (int k = 0; k < 3; ++k) {                                             // seg <= 10: at most 640 products
             const int e = tid + 256 * k, sx = e >> 6, r2 = blockIdx.x * 64 + (e & 63);
             cpre[k] = bld1(rC, (e < seg * 64 && r2 < H2) ? (unsigned)(((size_t)f * g.N + (size_t)(l * seg + sx) * H2 + r2) * 4) : SWN_OOB);
+        }
+        if (d16) {
+            // bf16 rows: a lane takes the dword (positions te, te + 1) with te = (tbeg & ~1) + 2 lane + 128 k - aligned whatever the
+            // parity of the frame's first position; (NCH + 1) / 2 chunks of 128 columns cover the tile (2-byte loads: 58 -> 231 us)
+            const int tal = tbeg & ~1;
+#pragma unroll
+            for (int k = 0; k < (NCH + 1) / 2; ++k) {
+                const int te = tal + 2 * lane + 128 * k;
+                const bool tok = te - tbeg < ncol && te + 1 >= 0 && te < a.Tp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int r2 = blockIdx.x * 64 + w + 4 * i;
+                    v[k][i] = bld1(rD, (tok && te >= 0 && r2 < H2) ? ((unsigned)r2 * (unsigned)a.da16_pitch + (unsigned)te) * 2u : SWN_OOB);
+                }
+            }
+            return;
         }
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -1147,6 +1165,20 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
     for (int f = blockIdx.y * FR; f < f1; ++f) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) { const int e = tid + 256 * k; if (e < seg * 64) cs[e >> 6][e & 63] = cpre[k]; }
+        if (d16) {
+            const int tbeg = f * U - (seg - 1) - a.coff, tal = tbeg & ~1;
+#pragma unroll
+            for (int k = 0; k < (NCH + 1) / 2; ++k) {
+                const int te = tal + 2 * lane + 128 * k, c0 = te - tbeg;         // columns c0 (may be -1) and c0 + 1
+                const bool k0 = c0 >= 0 && c0 < ncol && te >= 0 && te < a.Tp, k1 = c0 + 1 < ncol && te + 1 >= 0 && te + 1 < a.Tp;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const unsigned u = __float_as_uint(v[k][i]);
+                    if (c0 >= 0 && c0 < ncol) tile(w + 4 * i, c0) = k0 ? __uint_as_float(u << 16) : 0.f;
+                    if (c0 + 1 < ncol) tile(w + 4 * i, c0 + 1) = k1 ? __uint_as_float(u & 0xffff0000u) : 0.f;
+                }
+            }
+        } else {
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int c = lane + 64 * k;
@@ -1154,6 +1186,7 @@ __global__ __launch_bounds__(256) void cond_bwd_kernel(const GateBwd a, float* _
 #pragma unroll
                 for (int i = 0; i < 16; ++i) tile(w + 4 * i, c) = v[k][i];
             }
+        }
         }
         __syncthreads();
         if (f + 1 < f1) fetch(f + 1);
@@ -1903,6 +1936,10 @@ int backward_impl(const swn_net_desc* d, const float* packed, const float* aux, 
         ga.l = l;
         if (dgx_all) { dgx = dgx_all + (size_t)l * H2 * Tp; ga.dgx = dgx; ga.dgx_sb = (long)L * H2 * Tp; }
         if (dgx16_all) { ga.dgx16 = dgx16_all + (size_t)l * H2 * da16_pitch; ga.dgx16_sb = (long)L * H2 * da16_pitch; }
+        else if (!drop && a_keep && da16 && da16_pitch <= 2L * Tp) {   // GEMM-stack class, no dropout: cond_bwd_kernel reads the bf16 rows
+            // (same section, half of it; the small nets keep fp32 here: the rounding moved a 2e-2 gradient check of the 32-channel fixtures)
+            ga.dgx16 = reinterpret_cast<unsigned short*>(dgx); ga.dgx16_sb = (long)H2 * da16_pitch;
+        }
         // dropout mode: this layer's input is h_{l-1} times the mask drawn for layer l-1's output (cswnv_shift1.py:269-273)
         const float* in_mul = (drop && l > 0) ? drop_h[l - 1] : nullptr;
         ga.in_mul = in_mul;
