@@ -333,3 +333,44 @@ def test_gemm_stack_dropout_step_softmax_audio_in(gpu_ok):
     assert float((fwd["bf16"] - fwd["fp32"]).abs().max()) <= 2e-2 * max(1.0, float(fwd["fp32"].abs().max()))
     assert float((fwd["bf16"] - fwd["fp32"]).abs().max()) > 0, "the bf16 forward did not engage"
     _close("g16_softmax_audio_in", out["bf16"], {k: v.astype(np.float64) for k, v in out["fp32"].items()}, tol=1e-1, floor=5e-5)
+
+
+@pytest.mark.parametrize("geom", ["bl6", "ref6"])
+def test_loss_curves_of_the_arithmetic_modes_track_each_other(gpu_ok, geom):
+    """Twenty Adam steps on one fixed synthetic batch (tools/train_sanity.py in short): the mixed-precision mode - through the
+    fused backward where the geometry has one, and through the generic chain - must end within 2 % of the loss the exact-fp32
+    mode reaches, and every curve must descend.  """
+    cfg = C.bl6_laplace(1, 0) if geom == "bl6" else C.ref6_laplace(1, 4)
+    B, Tf, N = (4, 12, 20) if geom == "bl6" else (2, 8, 20)
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf)).cuda()
+    T = Tf * cfg.U
+    Tp = T - 2 * cfg.seg + 1
+    g = torch.Generator().manual_seed(2)
+    audio = (torch.rand(B, 1, T - cfg.seg, generator=g) * 0.6 - 0.3).cuda()
+    tgt = (torch.rand(B, Tp, generator=g) * 0.6 - 0.3).cuda()
+    sd = {k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=1, flavor="trained", identity_scale_in=True).items()}
+    curves = {}
+    for name, mode, fused in (("fp32", "fp32", True), ("bf16 chain", "bf16", False), ("bf16 fused", "bf16", True)):
+        m = mc.CSWNV(**cfg.ctor_kwargs())
+        m.load_state_dict(sd)
+        m.cuda().train()
+        for p in m.scale_in.parameters():
+            p.requires_grad = False
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        losses = []
+        with train_precision(mode):
+            for _ in range(N):
+                m._engine().fused_backward = fused
+                res = m(aux, audio)
+                loss = mc.LaplaceLoss()(res[0].reshape(B, Tp), res[1].reshape(B, Tp), tgt, log_b=res[2].reshape(B, Tp), log=False)
+                opt.zero_grad(set_to_none=True)
+                loss.backward()
+                opt.step()
+                losses.append(float(loss))
+        curves[name] = losses
+    ref = curves["fp32"]
+    assert ref[-1] < ref[0], ref
+    for name in ("bf16 chain", "bf16 fused"):
+        c = curves[name]
+        assert c[-1] < c[0], (name, c)
+        assert abs(c[-1] - ref[-1]) <= 2e-2 * max(abs(ref[-1]), 1e-3) + 2e-2 * abs(ref[0] - ref[-1]), (name, c[-1], ref[-1], ref[0])
