@@ -162,39 +162,47 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
     // accumulator element (i, j, r): tile row 64 wm + 16 i + 4 (lane/16) + r, tile column 64 wn + 16 j + lane%16
     const int g4 = lane >> 4, n = lane & 15;
     if (EPI == EPI_GATE) {
+        // Loop order: channel group outside, positions inside - the 16 per-channel constants of a lane are loaded once per group
+        // (inside the position loop every store to hnext stood between them and their reuse), and the conditioning frame of a
+        // position comes from one division per position, not one per (position, group, segment tap).
         const float* P = a.P;
         const int H = a.H, H2 = 2 * a.H, l = a.l;
+        int fj[WNT], jj0[WNT];
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
-            const int t = t0 + 16 * WNT * wn + 16 * j + n;
-            if (t >= a.Tp) continue;
+            const int tt = t0 + 16 * WNT * wn + 16 * j + n + a.coff;
+            fj[j] = tt / a.U; jj0[j] = tt - fj[j] * a.U;
+        }
 #pragma unroll
-            for (int p = 0; p < 2; ++p) {
-                const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
-                if (ch >= H) continue;
-                float gz[4], gc[4];
+        for (int p = 0; p < 2; ++p) {
+            const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
+            if (ch >= H) continue;
+            const size_t ob = (a.gx ? a.o_bxr : a.o_bx) + (size_t)l * H2 + ch;
+            const float4 bxz = *reinterpret_cast<const float4*>(P + ob), bxc = *reinterpret_cast<const float4*>(P + ob + H);
+            const float4 bdz = *reinterpret_cast<const float4*>(P + a.o_bd + (size_t)l * H2 + ch);
+            const float4 bdc = *reinterpret_cast<const float4*>(P + a.o_bd + (size_t)l * H2 + H + ch);
+            const float bz[4] = {bdz.x, bdz.y, bdz.z, bdz.w}, bc[4] = {bdc.x, bdc.y, bdc.z, bdc.w};
+#pragma unroll
+            for (int j = 0; j < WNT; ++j) {
+                const int t = t0 + 16 * WNT * wn + 16 * j + n;
+                if (t >= a.Tp) continue;
+                float gz[4] = {bxz.x, bxz.y, bxz.z, bxz.w}, gc[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
                 if (a.gx) {                                   // G4 layout (swn_geom.hpp): the lane's four channels are one 16-byte piece
                     const float4 gz4 = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + ch, t));
                     const float4 gc4 = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + H + ch, t));
-                    const float zz[4] = {gz4.x, gz4.y, gz4.z, gz4.w}, cc[4] = {gc4.x, gc4.y, gc4.z, gc4.w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        gz[r] = zz[r] + P[a.o_bxr + (size_t)l * H2 + ch + r];
-                        gc[r] = cc[r] + P[a.o_bxr + (size_t)l * H2 + H + ch + r];
-                    }
+                    gz[0] += gz4.x; gz[1] += gz4.y; gz[2] += gz4.z; gz[3] += gz4.w;
+                    gc[0] += gc4.x; gc[1] += gc4.y; gc[2] += gc4.z; gc[3] += gc4.w;
                 } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) { gz[r] = P[a.o_bx + (size_t)l * H2 + ch + r]; gc[r] = P[a.o_bx + (size_t)l * H2 + H + ch + r]; }
-                }
-                for (int s = 0; s < (a.gx ? 0 : a.seg); ++s) {
-                    const int tt = t + s + a.coff;
-                    int f = tt / a.U; const int jj = tt - f * a.U;
-                    f = f < a.Tf ? f : a.Tf - 1;
-                    const float wu = P[a.o_wup + jj];
-                    const float* cr = a.cond + ((size_t)b * a.Tf + f) * a.N + (size_t)(l * a.seg + s) * H2 + ch;
-                    const float4 cz = *reinterpret_cast<const float4*>(cr), cc = *reinterpret_cast<const float4*>(cr + H);
-                    gz[0] = fmaf(wu, cz.x, gz[0]); gz[1] = fmaf(wu, cz.y, gz[1]); gz[2] = fmaf(wu, cz.z, gz[2]); gz[3] = fmaf(wu, cz.w, gz[3]);
-                    gc[0] = fmaf(wu, cc.x, gc[0]); gc[1] = fmaf(wu, cc.y, gc[1]); gc[2] = fmaf(wu, cc.z, gc[2]); gc[3] = fmaf(wu, cc.w, gc[3]);
+                    int f = fj[j], jj = jj0[j];
+                    for (int s = 0; s < a.seg; ++s) {
+                        const int fc = f < a.Tf ? f : a.Tf - 1;
+                        const float wu = P[a.o_wup + jj];
+                        const float* cr = a.cond + ((size_t)b * a.Tf + fc) * a.N + (size_t)(l * a.seg + s) * H2 + ch;
+                        const float4 cz = *reinterpret_cast<const float4*>(cr), cc = *reinterpret_cast<const float4*>(cr + H);
+                        gz[0] = fmaf(wu, cz.x, gz[0]); gz[1] = fmaf(wu, cz.y, gz[1]); gz[2] = fmaf(wu, cz.z, gz[2]); gz[3] = fmaf(wu, cz.w, gz[3]);
+                        gc[0] = fmaf(wu, cc.x, gc[0]); gc[1] = fmaf(wu, cc.y, gc[1]); gc[2] = fmaf(wu, cc.z, gc[2]); gc[3] = fmaf(wu, cc.w, gc[3]);
+                        if (++jj >= a.U) { jj = 0; ++f; }
+                    }
                 }
                 if (a.aidx) {                                 // one-hot audio input columns of in_x (dswnv.py:255-256)
                     int idx = a.aidx[(size_t)b * a.Tp + t] % a.Q; idx = idx < 0 ? idx + a.Q : idx;
@@ -214,8 +222,7 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float z, c;
-                    gate_zc(gz[r] * (acc[2 * p][j][r] + P[a.o_bd + (size_t)l * H2 + ch + r]),
-                            gc[r] * (acc[2 * p + 1][j][r] + P[a.o_bd + (size_t)l * H2 + H + ch + r]), z, c);
+                    gate_zc(gz[r] * (acc[2 * p][j][r] + bz[r]), gc[r] * (acc[2 * p + 1][j][r] + bc[r]), z, c);
                     hv[r] = f2bf((1.f - z) * c + z * hp[r]);
                 }
                 uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
