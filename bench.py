@@ -349,12 +349,15 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
     with train_precision(mode):
         for _ in range(4):                       # the caching allocator needs a few steps to settle after the previous leg
             step()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            step()
-        torch.cuda.synchronize()
-        ms = (time.perf_counter() - t0) / reps * 1e3
+        blocks = []                              # median of three blocks: one allocator stall inside a block of 2-5 steps
+        for _ in range(3):                       # read as a 5x slower step in a driver run once
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                step()
+            torch.cuda.synchronize()
+            blocks.append((time.perf_counter() - t0) / reps * 1e3)
+        ms = sorted(blocks)[1]
         ms_nopt = _hip_timed(lambda: step(False), reps, warm=1)
     pos = B * Tp
     flops = 3 * 2.0 * stack_macs_per_position(cfg) * pos
