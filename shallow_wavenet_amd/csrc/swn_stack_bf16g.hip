@@ -64,6 +64,110 @@ struct GemmArgs {
                                                    // instead of the hoisted cond, + the raw in_x bias (cswnv_shift1.py:194-198,269-278)
 };
 
+// ---- gate epilogue, shared by the two layer kernels.  A lane finishes 4 consecutive channels ch .. ch+3 (gate pre-activations az,
+// candidate pre-activations ac) of one position t: hoisted conditioning (or the dropout mode's sample-rate in_x rows), sigmoid / tanh,
+// the highway mix, one 8-byte bf16 store; the kept pre-activations of the training mode leave as two 16-byte pieces (G4 layout).
+struct GateCh { float4 bxz, bxc, bdz, bdc; };       // per-channel constants of a lane's group, loaded once per group
+__device__ __forceinline__ GateCh gate_consts(const GemmArgs& a, const int ch) {
+    const int H = a.H, H2 = 2 * a.H;
+    const size_t ob = (a.gx ? a.o_bxr : a.o_bx) + (size_t)a.l * H2 + ch;
+    GateCh k;
+    k.bxz = *reinterpret_cast<const float4*>(a.P + ob); k.bxc = *reinterpret_cast<const float4*>(a.P + ob + H);
+    k.bdz = *reinterpret_cast<const float4*>(a.P + a.o_bd + (size_t)a.l * H2 + ch);
+    k.bdc = *reinterpret_cast<const float4*>(a.P + a.o_bd + (size_t)a.l * H2 + H + ch);
+    return k;
+}
+// One channel group (4 channels from ch) at NJ positions tb, tb + 16, ...: EVERY operand load of the group is issued before the
+// first store - written position by position, each store to hnext stood between the next position's loads and their use (the
+// compiler cannot know that hnext aliases none of them), i.e. one memory round trip per position and group: 18 in a row for a lane
+// of the 384-row kernel, with nothing else on the CU to hide them.  Loads of positions past the end are clamped (never stored).
+// (fj, jj0) = conditioning frame and upsampler tap of position t + coff (one division per position, done by the caller).
+template <int NJ>
+__device__ __forceinline__ void gate_group(const GemmArgs& a, const int b, const int ch, const int tb, const int (&fj)[NJ],
+                                           const int (&jj0)[NJ], const f32x4 (&az)[NJ], const f32x4 (&ac)[NJ]) {
+    const float* P = a.P;
+    const int H = a.H, H2 = 2 * a.H, l = a.l;
+    const GateCh k = gate_consts(a, ch);
+    const float bz[4] = {k.bdz.x, k.bdz.y, k.bdz.z, k.bdz.w}, bc[4] = {k.bdc.x, k.bdc.y, k.bdc.z, k.bdc.w};
+    float gz[NJ][4], gc[NJ][4];
+    int tc[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = tb + 16 * j;
+        tc[j] = t < a.Tp ? t : a.Tp - 1;
+        gz[j][0] = k.bxz.x; gz[j][1] = k.bxz.y; gz[j][2] = k.bxz.z; gz[j][3] = k.bxz.w;
+        gc[j][0] = k.bxc.x; gc[j][1] = k.bxc.y; gc[j][2] = k.bxc.z; gc[j][3] = k.bxc.w;
+    }
+    if (a.gx) {                                   // G4 layout (swn_geom.hpp): the lane's four channels are one 16-byte piece
+        float4 gz4[NJ], gc4[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            gz4[j] = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + ch, tc[j]));
+            gc4[j] = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + H + ch, tc[j]));
+        }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            gz[j][0] += gz4[j].x; gz[j][1] += gz4[j].y; gz[j][2] += gz4[j].z; gz[j][3] += gz4[j].w;
+            gc[j][0] += gc4[j].x; gc[j][1] += gc4[j].y; gc[j][2] += gc4[j].z; gc[j][3] += gc4[j].w;
+        }
+    } else {
+        int f[NJ], jj[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { f[j] = fj[j]; jj[j] = jj0[j]; }
+        for (int s = 0; s < a.seg; ++s) {
+            float wu[NJ]; float4 cz[NJ], cc[NJ];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int fc = f[j] < a.Tf ? f[j] : a.Tf - 1;
+                wu[j] = P[a.o_wup + jj[j]];
+                const float* cr = a.cond + ((size_t)b * a.Tf + fc) * a.N + (size_t)(l * a.seg + s) * H2 + ch;
+                cz[j] = *reinterpret_cast<const float4*>(cr); cc[j] = *reinterpret_cast<const float4*>(cr + H);
+                if (++jj[j] >= a.U) { jj[j] = 0; ++f[j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                gz[j][0] = fmaf(wu[j], cz[j].x, gz[j][0]); gz[j][1] = fmaf(wu[j], cz[j].y, gz[j][1]);
+                gz[j][2] = fmaf(wu[j], cz[j].z, gz[j][2]); gz[j][3] = fmaf(wu[j], cz[j].w, gz[j][3]);
+                gc[j][0] = fmaf(wu[j], cc[j].x, gc[j][0]); gc[j][1] = fmaf(wu[j], cc[j].y, gc[j][1]);
+                gc[j][2] = fmaf(wu[j], cc[j].z, gc[j][2]); gc[j][3] = fmaf(wu[j], cc[j].w, gc[j][3]);
+            }
+        }
+    }
+    if (a.aidx) {                                 // one-hot audio input columns of in_x (dswnv.py:255-256)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            int idx = a.aidx[(size_t)b * a.Tp + tc[j]] % a.Q; idx = idx < 0 ? idx + a.Q : idx;
+            const float* wa = P + a.o_wxa + ((size_t)l * a.Q + idx) * H2 + ch;
+            const float4 az4 = *reinterpret_cast<const float4*>(wa), ac4 = *reinterpret_cast<const float4*>(wa + H);
+            gz[j][0] += az4.x; gz[j][1] += az4.y; gz[j][2] += az4.z; gz[j][3] += az4.w;
+            gc[j][0] += ac4.x; gc[j][1] += ac4.y; gc[j][2] += ac4.z; gc[j][3] += ac4.w;
+        }
+    }
+    uint2 hp2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) hp2[j] = *reinterpret_cast<const uint2*>(a.hprev + ((size_t)b * a.Tp + tc[j]) * H + ch);
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = tb + 16 * j;
+        if (t >= a.Tp) continue;
+        const float hp[4] = {bf2f((unsigned short)(hp2[j].x & 0xffff)), bf2f((unsigned short)(hp2[j].x >> 16)),
+                             bf2f((unsigned short)(hp2[j].y & 0xffff)), bf2f((unsigned short)(hp2[j].y >> 16))};
+        if (a.a_out) {     // training: the backward reads these instead of recomputing the dilated conv (G4 layout: 16-byte pieces)
+            *reinterpret_cast<f32x4*>(a.a_out + swn_g4(H2, a.Tp, b, ch, t)) = az[j];
+            *reinterpret_cast<f32x4*>(a.a_out + swn_g4(H2, a.Tp, b, H + ch, t)) = ac[j];
+        }
+        unsigned short hv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float z, c;
+            gate_zc(gz[j][r] * (az[j][r] + bz[r]), gc[j][r] * (ac[j][r] + bc[r]), z, c);
+            hv[r] = f2bf((1.f - z) * c + z * hp[r]);
+        }
+        uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
+        *reinterpret_cast<uint2*>(a.hnext + ((size_t)b * a.Tp + t) * H + ch) = o;
+    }
+}
+
 // Three workgroups per CU (launch bound: 138 registers, accumulators included) with two register stages beat two workgroups with
 // three stages (208 registers): 296 -> 274 us per gated layer at REF6 - these loops wait on memory round trips, and a third
 // workgroup hides more of them than a third stage.
@@ -165,8 +269,6 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
         // Loop order: channel group outside, positions inside - the 16 per-channel constants of a lane are loaded once per group
         // (inside the position loop every store to hnext stood between them and their reuse), and the conditioning frame of a
         // position comes from one division per position, not one per (position, group, segment tap).
-        const float* P = a.P;
-        const int H = a.H, H2 = 2 * a.H, l = a.l;
         int fj[WNT], jj0[WNT];
 #pragma unroll
         for (int j = 0; j < WNT; ++j) {
@@ -176,58 +278,11 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
-            if (ch >= H) continue;
-            const size_t ob = (a.gx ? a.o_bxr : a.o_bx) + (size_t)l * H2 + ch;
-            const float4 bxz = *reinterpret_cast<const float4*>(P + ob), bxc = *reinterpret_cast<const float4*>(P + ob + H);
-            const float4 bdz = *reinterpret_cast<const float4*>(P + a.o_bd + (size_t)l * H2 + ch);
-            const float4 bdc = *reinterpret_cast<const float4*>(P + a.o_bd + (size_t)l * H2 + H + ch);
-            const float bz[4] = {bdz.x, bdz.y, bdz.z, bdz.w}, bc[4] = {bdc.x, bdc.y, bdc.z, bdc.w};
+            if (ch >= a.H) continue;
 #pragma unroll
-            for (int j = 0; j < WNT; ++j) {
-                const int t = t0 + 16 * WNT * wn + 16 * j + n;
-                if (t >= a.Tp) continue;
-                float gz[4] = {bxz.x, bxz.y, bxz.z, bxz.w}, gc[4] = {bxc.x, bxc.y, bxc.z, bxc.w};
-                if (a.gx) {                                   // G4 layout (swn_geom.hpp): the lane's four channels are one 16-byte piece
-                    const float4 gz4 = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + ch, t));
-                    const float4 gc4 = *reinterpret_cast<const float4*>(a.gx + swn_g4(a.gx_rows, a.Tp, b, l * H2 + H + ch, t));
-                    gz[0] += gz4.x; gz[1] += gz4.y; gz[2] += gz4.z; gz[3] += gz4.w;
-                    gc[0] += gc4.x; gc[1] += gc4.y; gc[2] += gc4.z; gc[3] += gc4.w;
-                } else {
-                    int f = fj[j], jj = jj0[j];
-                    for (int s = 0; s < a.seg; ++s) {
-                        const int fc = f < a.Tf ? f : a.Tf - 1;
-                        const float wu = P[a.o_wup + jj];
-                        const float* cr = a.cond + ((size_t)b * a.Tf + fc) * a.N + (size_t)(l * a.seg + s) * H2 + ch;
-                        const float4 cz = *reinterpret_cast<const float4*>(cr), cc = *reinterpret_cast<const float4*>(cr + H);
-                        gz[0] = fmaf(wu, cz.x, gz[0]); gz[1] = fmaf(wu, cz.y, gz[1]); gz[2] = fmaf(wu, cz.z, gz[2]); gz[3] = fmaf(wu, cz.w, gz[3]);
-                        gc[0] = fmaf(wu, cc.x, gc[0]); gc[1] = fmaf(wu, cc.y, gc[1]); gc[2] = fmaf(wu, cc.z, gc[2]); gc[3] = fmaf(wu, cc.w, gc[3]);
-                        if (++jj >= a.U) { jj = 0; ++f; }
-                    }
-                }
-                if (a.aidx) {                                 // one-hot audio input columns of in_x (dswnv.py:255-256)
-                    int idx = a.aidx[(size_t)b * a.Tp + t] % a.Q; idx = idx < 0 ? idx + a.Q : idx;
-                    const float* wa = P + a.o_wxa + ((size_t)l * a.Q + idx) * H2 + ch;
-                    const float4 az4 = *reinterpret_cast<const float4*>(wa), ac4 = *reinterpret_cast<const float4*>(wa + H);
-                    gz[0] += az4.x; gz[1] += az4.y; gz[2] += az4.z; gz[3] += az4.w;
-                    gc[0] += ac4.x; gc[1] += ac4.y; gc[2] += ac4.z; gc[3] += ac4.w;
-                }
-                const uint2 hp2 = *reinterpret_cast<const uint2*>(a.hprev + ((size_t)b * a.Tp + t) * H + ch);
-                const float hp[4] = {bf2f((unsigned short)(hp2.x & 0xffff)), bf2f((unsigned short)(hp2.x >> 16)),
-                                     bf2f((unsigned short)(hp2.y & 0xffff)), bf2f((unsigned short)(hp2.y >> 16))};
-                if (a.a_out) {     // training: the backward reads these instead of recomputing the dilated conv (G4 layout: 16-byte pieces)
-                    *reinterpret_cast<f32x4*>(a.a_out + swn_g4(H2, a.Tp, b, ch, t)) = acc[2 * p][j];
-                    *reinterpret_cast<f32x4*>(a.a_out + swn_g4(H2, a.Tp, b, H + ch, t)) = acc[2 * p + 1][j];
-                }
-                unsigned short hv[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float z, c;
-                    gate_zc(gz[r] * (acc[2 * p][j][r] + bz[r]), gc[r] * (acc[2 * p + 1][j][r] + bc[r]), z, c);
-                    hv[r] = f2bf((1.f - z) * c + z * hp[r]);
-                }
-                uint2 o; o.x = hv[0] | ((unsigned)hv[1] << 16); o.y = hv[2] | ((unsigned)hv[3] << 16);
-                *reinterpret_cast<uint2*>(a.hnext + ((size_t)b * a.Tp + t) * H + ch) = o;
-            }
+            for (int j0 = 0; j0 < WNT; j0 += 2)      // two positions per batch: four would spill under the three-workgroup register bound
+                gate_group<2>(a, b, ch, t0 + 16 * WNT * wn + 16 * j0 + n, reinterpret_cast<const int (&)[2]>(fj[j0]), reinterpret_cast<const int (&)[2]>(jj0[j0]),
+                              reinterpret_cast<const f32x4 (&)[2]>(acc[2 * p][j0]), reinterpret_cast<const f32x4 (&)[2]>(acc[2 * p + 1][j0]));
         }
     } else {
 #pragma unroll
@@ -268,6 +323,147 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
                     if (m + r < a.NO) a.out_f[((size_t)b * a.NO + m + r) * a.Tp + t] = acc[i][j][r] + (a.bias ? a.bias[m + r] : 0.f);
             }
         }
+    }
+}
+
+// ---- gated layer of the H = 192 geometry (run.sh Laplace net: M = 2H = 384 rows, K = 7 x 192) with LDS-DMA staging ----------
+// The 128 x 128 kernel above stages through registers behind two barriers per k-tile and hides its waits behind three workgroups
+// per CU; what it cannot hide is that every byte passes a VGPR and an LDS store, and that M = 384 re-reads each activation tile
+// three times.  Here ONE 512-thread workgroup per CU owns all 384 rows of a 32 NCW-position tile:
+//   * operands go global -> LDS without touching a register (`buffer_load_dwordx4 ... lds`, dma_piece below): a stage is one
+//     k-tile of 32 (24 + 2 NCW pieces of 1 KiB = 16 rows of 64 bytes, unpadded); the k-octets of a row are permuted at the source
+//     so that the fragment reads are conflict-free (see the lane maps in the kernel);
+//   * four stages in a ring, three in flight, ONE barrier per stage: a wave waits for its own pieces of stage kt with a counted
+//     vmcnt (the two younger stages stay in flight), the barrier publishes everybody's, and the stage after next goes into the slot
+//     the barrier has just freed.  Stages past the end are issued all out-of-range (they land as zeros in a free slot), so the
+//     count is the same in every iteration;
+//   * wave (wm, wn) owns rows [96 wm, 96 wm + 96) = channels [48 wm, 48 wm + 48) as [gate 16 | cand 16] x 3 and NCW column
+//     fragments: 6 + NCW fragment reads feed 6 NCW MFMAs per stage (the 64 x 64 wave tile above: 8 reads for 16);
+//   * causal zero padding and the ragged last tile are out-of-range lanes of the DMA (zeros), as everywhere in this file.
+// NCW = 6 (192 positions, 144 KB of LDS) or 4 (128 positions, 128 KB): the launcher takes whichever wastes fewer tile rounds.
+typedef int g8_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void g8_dma(const g8_v4i rsrc, unsigned voff, unsigned soff, unsigned lds_base) {
+    // lane i's 16 bytes land at lds_base + 16 i; the range check is on voff (out of range: zeros); M0 carries the LDS base
+    asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %2 offen lds"
+                 :: "v"(voff), "s"(rsrc), "s"(__builtin_amdgcn_readfirstlane((int)soff)),
+                    "s"(__builtin_amdgcn_readfirstlane((int)lds_base)) : "memory");
+}
+__device__ __forceinline__ g8_v4i g8_rsrc(const void* p, size_t bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(p);
+    g8_v4i r;
+    r.x = __builtin_amdgcn_readfirstlane((int)(unsigned)(a & 0xffffffffull));
+    r.y = __builtin_amdgcn_readfirstlane((int)(unsigned)((a >> 32) & 0xffffull));
+    r.z = __builtin_amdgcn_readfirstlane((int)(unsigned)bytes);
+    r.w = 0x00020000;
+    return r;
+}
+constexpr int G8_ST = 4;                        // stages of the ring
+template <int NCW>
+__global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, const int ntiles) {
+    constexpr int BN = 32 * NCW, AB = 24, BB = BN / 16;
+    constexpr unsigned STB = (unsigned)(AB + BB) * 1024u;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // ALL LDS of the kernel is this one block
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
+    const int n = lane & 15, g4 = lane >> 4;
+    // DMA lane i fetches row i >> 2, k-octet (i & 3) ^ G8_SW(row >> 2) of its piece: four consecutive lanes = the 64 contiguous bytes
+    // of one row (one request; row i & 15 per lane made 64 requests of 16 bytes per instruction and ran at half the speed), and
+    // the octet permutation makes the fragment read - lane (n, g4) at 64 n + 16 (g4 ^ G8_SW(n >> 2)) - conflict-free in each of
+    // the four 16-lane groups a ds_read_b128 is served in (MI355X_MICROARCH.md, LDS table)
+    const int dr = lane >> 2, dk = ((lane & 3) ^ ((0x1320 >> (4 * (dr >> 2))) & 3)) * 8;       // G8_SW = {0, 2, 3, 1}
+    const unsigned rdl = (unsigned)(64 * n + 16 * (g4 ^ ((0x1320 >> (4 * (n >> 2))) & 3)));
+    // XCD-aware order (workgroup id i runs on XCD i % 8): each XCD walks a contiguous range of time tiles
+    const int chunk = (ntiles + 7) / 8;
+    const int gt = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || gt >= ntiles) return;
+    const int b = gt / a.ntt, t0 = (gt - b * a.ntt) * BN;
+    const int H = a.H;
+    const g8_v4i rA = g8_rsrc(a.A, (size_t)a.M * a.Kd * 2), rB = g8_rsrc(a.src, a.src_bytes);
+    // A pieces of this wave: blocks w, w + 8, w + 16 (block q = tile rows 16 q ..: wave q / 6, fragment q % 6)
+    unsigned avo[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int q = w + 8 * j, qm = q / 6, qi = q - 6 * qm;
+        const int row = (qi & 1) * H + 48 * qm + 16 * (qi >> 1) + dr;
+        avo[j] = (unsigned)(((size_t)row * a.Kd + dk) * 2);
+    }
+    // B pieces: block w, and block 8 + w on the waves below BB - 8
+    const bool two = BB > 8 && w < BB - 8;
+    int btl[2]; int bvo[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        btl[j] = t0 + 16 * (w + 8 * j) + dr;
+        bvo[j] = (int)((((size_t)b * a.Tp + btl[j]) * H + dk) * 2);
+    }
+    const int kpb = a.KB / 32, nk = a.nblk * kpb;
+    // one piece of stage kt (pc = 0..2: A, 3 / 4: B); the pieces of a stage are issued BETWEEN the MFMA rows of the stage in progress:
+    // a piece holds its wave's issue for 60-180 cycles (MI355X_MICROARCH.md, cycle constants), which the other wave of the SIMD
+    // fills with its MFMAs only if the pieces are not all issued at once behind the barrier, where both waves stand
+    int iblk = 0, ikin = 0;                      // block (tap) and channel offset of the stage being issued
+    auto piece = [&](const int kt, const int pc) __attribute__((always_inline)) {
+        const unsigned base = (unsigned)(kt & (G8_ST - 1)) * STB;
+        const bool live = kt < nk;
+        if (pc < 3) { g8_dma(rA, live ? avo[pc] : OOB, live ? (unsigned)kt * 64u : 0u, base + (unsigned)(w + 8 * pc) * 1024u); return; }
+        const int shift = a.shift0 - iblk * a.shift_step;
+        const int sk = (int)(((long)iblk * (long)a.blk_stride + (long)ikin - (long)shift * H) * 2);
+        if (pc == 3) g8_dma(rB, (live && btl[0] >= shift) ? (unsigned)(bvo[0] + sk) : OOB, 0u, base + (unsigned)(AB + w) * 1024u);
+        else {
+            if (two) g8_dma(rB, (live && btl[1] >= shift) ? (unsigned)(bvo[1] + sk) : OOB, 0u, base + (unsigned)(AB + 8 + w) * 1024u);
+            ikin += 32; if (ikin >= a.KB) { ikin = 0; ++iblk; }
+        }
+    };
+    auto issue = [&](const int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int pc = 0; pc < 5; ++pc) piece(kt, pc);
+    };
+    f32x4 acc[6][NCW];
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    issue(0); issue(1); issue(2);
+    const unsigned rd_a = (unsigned)(6 * wm) * 1024u + rdl, rd_b = (unsigned)(AB + NCW * wn) * 1024u + rdl;
+    for (int kt = 0; kt < nk; ++kt) {
+        // my pieces of stage kt have landed (two younger stages of 5 / 4 pieces stay in flight) ...
+        if (two) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and my fragment reads of stage kt - 1 are back
+        __builtin_amdgcn_s_barrier();                            // everybody's: stage kt readable, slot (kt - 1) & 3 free
+        asm volatile("" ::: "memory");
+        const unsigned char* sb = lds + (unsigned)(kt & (G8_ST - 1)) * STB;
+        bf16x8 af[6], bfr[NCW];
+#pragma unroll
+        for (int j = 0; j < NCW; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + rd_b + j * 1024);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + rd_a + i * 1024);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+#pragma unroll
+            for (int j = 0; j < NCW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (i < 5) {                                         // stage kt + 3 goes into the slot the barrier has just freed
+                __builtin_amdgcn_sched_barrier(0);
+                piece(kt + 3, i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the all-zero stages past the end may still be landing
+    // ---- gate epilogue: accumulator (i, j, r) = row 96 wm + 16 i + 4 g4 + r (i even: gate, odd: candidate of channels
+    // 48 wm + 16 (i >> 1) + 4 g4 + r), position t0 + 16 NCW wn + 16 j + n
+    int fj[NCW], jj0[NCW];
+#pragma unroll
+    for (int j = 0; j < NCW; ++j) {
+        const int tt = t0 + 16 * NCW * wn + 16 * j + n + a.coff;
+        fj[j] = tt / a.U; jj0[j] = tt - fj[j] * a.U;
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        const int ch = 48 * wm + 16 * p + 4 * g4;
+        constexpr int JB = 2;                        // positions per batch of loads (three spill beside the 144 accumulator registers)
+#pragma unroll
+        for (int j0 = 0; j0 < NCW; j0 += JB)
+            gate_group<JB>(a, b, ch, t0 + 16 * NCW * wn + 16 * j0 + n, reinterpret_cast<const int (&)[JB]>(fj[j0]), reinterpret_cast<const int (&)[JB]>(jj0[j0]),
+                           reinterpret_cast<const f32x4 (&)[JB]>(acc[2 * p][j0]), reinterpret_cast<const f32x4 (&)[JB]>(acc[2 * p + 1][j0]));
     }
 }
 
@@ -405,6 +601,29 @@ void launch_gemm(GemmArgs a, int ntt, int nmt, int batch, hipStream_t st) {
     a.ntt = ntt; a.nmt = nmt;
     const int chunk = (ntt * batch + 7) / 8;
     hipLaunchKernelGGL((bf16g_gemm_kernel<EPI, WNT>), dim3((unsigned)(8 * chunk * nmt)), dim3(256), 0, st, a);
+}
+
+// the LDS-DMA gated layer (M = 384): tile width by fewer wasted rounds over the CUs; false = not launched (attribute refused)
+bool launch_gate8(GemmArgs a, int batch, hipStream_t st) {
+    static int ncu = 0; static bool attr_ok[2] = {false, false};
+    if (!ncu) {
+        int dev = 0; hipDeviceProp_t pr;
+        ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    auto rounds_cost = [&](int bn) { const long tiles = (long)batch * ((a.Tp + bn - 1) / bn); return ((tiles + ncu - 1) / ncu) * bn; };
+    const bool wide = rounds_cost(192) <= rounds_cost(128);
+    const int bn = wide ? 192 : 128;
+    const size_t ldsb = (size_t)G8_ST * (24 + bn / 16) * 1024;
+    const void* fn = wide ? reinterpret_cast<const void*>(bf16g_gate8_kernel<6>) : reinterpret_cast<const void*>(bf16g_gate8_kernel<4>);
+    if (!attr_ok[wide]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) { (void)hipGetLastError(); return false; }
+        attr_ok[wide] = true;
+    }
+    a.ntt = (a.Tp + bn - 1) / bn; a.nmt = 1;
+    const int ntiles = a.ntt * batch, chunk = (ntiles + 7) / 8;
+    if (wide) hipLaunchKernelGGL(bf16g_gate8_kernel<6>, dim3((unsigned)(8 * chunk)), dim3(512), ldsb, st, a, ntiles);
+    else hipLaunchKernelGGL(bf16g_gate8_kernel<4>, dim3((unsigned)(8 * chunk)), dim3(512), ldsb, st, a, ntiles);
+    return true;
 }
 
 }  // namespace
@@ -564,6 +783,7 @@ int swn_bf16g_forward(const SwnGeom& g, const float* packed, const void* wbf_, c
             a.src = hm16; a.hprev = hm16;
         }
         a.a_out = a_keep ? a_keep + (size_t)l * (((size_t)batch * 2 * g.H * Tp + 63) & ~(size_t)63) : nullptr;
+        if (g.H == 192 && a.KB == 192 && launch_gate8(a, batch, st)) continue;      // LDS-DMA layer kernel of the run.sh Laplace geometry
         launch_gemm<EPI_GATE>(a, (int)tx, g.H / 64, batch, st);
     }
     a.a_out = nullptr;
