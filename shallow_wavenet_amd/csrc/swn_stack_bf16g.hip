@@ -448,6 +448,18 @@ __global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, cons
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // the all-zero stages past the end may still be landing
+#ifdef SWN_G8_NOEPI          // diagnostic build (tools/build_variant.sh, tools/ab_variants.sh): the main loop alone - one store keeps the accumulators live
+    {
+        f32x4 sum = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int j = 0; j < NCW; ++j) sum += acc[i][j];
+        const int t = t0 + 16 * NCW * wn + n;
+        if (t < a.Tp) *reinterpret_cast<uint2*>(a.hnext + ((size_t)b * a.Tp + t) * H + 48 * wm + 4 * g4) = make_uint2(__float_as_uint(sum[0] + sum[1]), __float_as_uint(sum[2] + sum[3]));
+        return;
+    }
+#endif
     // ---- gate epilogue: accumulator (i, j, r) = row 96 wm + 16 i + 4 g4 + r (i even: gate, odd: candidate of channels
     // 48 wm + 16 (i >> 1) + 4 g4 + r), position t0 + 16 NCW wn + 16 j + n
     int fj[NCW], jj0[NCW];
