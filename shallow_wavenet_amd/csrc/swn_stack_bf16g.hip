@@ -198,14 +198,17 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
         const int ch = c0 + 32 * wmr + 16 * (mt >> 1) + r;
         return ch < a.H ? (mt & 1) * a.H + ch : -1;
     };
-    // staging: thread -> (row = tid/2, half = tid%2): 2 x 16 bytes of a 64-byte k-tile row, for A and for B
-    const int sr = tid >> 1, sh = tid & 1;
-    const int arow = rowmap(sr);
-    const bool aok = arow >= 0 && arow < a.M;
+    // staging: thread -> (row = tid/4 (+64), 16-byte piece = tid%4) of a 64-byte k-tile row, for A and for B: four consecutive lanes
+    // fetch the 64 contiguous bytes of one row (one request; with a lane pair per row - two pieces 32 bytes apart per instruction -
+    // every piece was a request of its own)
+    const int sr = tid >> 2, sq = tid & 3;
+    int arow[2]; bool aok[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) { arow[h] = rowmap(sr + 64 * h); aok[h] = arow[h] >= 0 && arow[h] < a.M; }
     const int tpos = t0 + sr;
     const int ktiles_per_blk = a.KB / TK, nk = a.nblk * ktiles_per_blk;
     constexpr int NST = 2;                      // k-tiles in flight per thread (register stages)
-    constexpr int BQ = WNT / 4;                 // B rows staged per thread (128 rows per pass)
+    constexpr int BQ = WNT / 4;                 // 128-row passes over the B tile
     uint4 ra[NST][2], rb[NST][2 * BQ];
     // branch-free AND select-free: operands come through buffer resources, and everything that must read as zero
     // (a k-tile past the end of the padded k loop, a row past M, a position outside the sequence) is an
@@ -214,19 +217,20 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.A), 0, (unsigned)((size_t)a.M * a.Kd * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(a.src), 0, (unsigned)a.src_bytes, 0x00020000);
     constexpr unsigned OOB = 0x80000000u;
-    const unsigned a_off = aok ? (unsigned)(((size_t)arow * a.Kd + 16 * sh) * 2) : OOB;
+    unsigned a_off[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a_off[h] = aok[h] ? (unsigned)(((size_t)arow[h] * a.Kd + 8 * sq) * 2) : OOB;
     auto ld16 = [&](__amdgpu_buffer_rsrc_t r, unsigned off) { return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0)); };
     auto fetch = [&](int kt, uint4 (&qa)[2], uint4 (&qb)[2 * BQ]) {
         const bool live = kt < nk;
         const int blk = kt / ktiles_per_blk, kin = (kt - blk * ktiles_per_blk) * TK;
-        const unsigned oa = (live && aok) ? a_off + (unsigned)kt * (TK * 2) : OOB;
-        qa[0] = ld16(rA, oa); qa[1] = ld16(rA, oa + 16u);
 #pragma unroll
-        for (int q = 0; q < BQ; ++q) {
-            const int tp = tpos + 128 * q, ts = tp - (a.shift0 - blk * a.shift_step);
+        for (int h = 0; h < 2; ++h) qa[h] = ld16(rA, (live && aok[h]) ? a_off[h] + (unsigned)kt * (TK * 2) : OOB);
+#pragma unroll
+        for (int q = 0; q < 2 * BQ; ++q) {
+            const int tp = tpos + 64 * q, ts = tp - (a.shift0 - blk * a.shift_step);
             const bool bok = live && tp < a.Tp && ts >= 0;
-            const unsigned ob = bok ? (unsigned)(((size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 16 * sh) * 2) : OOB;
-            qb[2 * q] = ld16(rB, ob); qb[2 * q + 1] = ld16(rB, ob + 16u);
+            qb[q] = ld16(rB, bok ? (unsigned)(((size_t)blk * a.blk_stride + ((size_t)b * a.Tp + ts) * a.KB + kin + 8 * sq) * 2) : OOB);
         }
     };
     f32x4 acc[4][WNT];
@@ -240,13 +244,10 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
 #pragma unroll
         for (int u = 0; u < NST; ++u) {
             const int kt = kt0 + u;                          // tiles past nk are all-zero operands: no branch in the loop
-            *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh) = ra[u][0];
-            *reinterpret_cast<uint4*>(As + sr * PITCH + 16 * sh + 8) = ra[u][1];
+            *reinterpret_cast<uint4*>(As + sr * PITCH + 8 * sq) = ra[u][0];
+            *reinterpret_cast<uint4*>(As + (sr + 64) * PITCH + 8 * sq) = ra[u][1];
 #pragma unroll
-            for (int q = 0; q < BQ; ++q) {
-                *reinterpret_cast<uint4*>(Bs + (sr + 128 * q) * PITCH + 16 * sh) = rb[u][2 * q];
-                *reinterpret_cast<uint4*>(Bs + (sr + 128 * q) * PITCH + 16 * sh + 8) = rb[u][2 * q + 1];
-            }
+            for (int q = 0; q < 2 * BQ; ++q) *reinterpret_cast<uint4*>(Bs + (sr + 64 * q) * PITCH + 8 * sq) = rb[u][q];
             __syncthreads();
             fetch(kt + NST, ra[u], rb[u]);             // refill the stage just consumed: NST k-tiles of loads in flight
             bf16x8 af[4], bfr[WNT];
