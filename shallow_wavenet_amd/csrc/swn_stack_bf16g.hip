@@ -358,12 +358,17 @@ __device__ __forceinline__ g8_v4i g8_rsrc(const void* p, size_t bytes) {
     r.w = 0x00020000;
     return r;
 }
-constexpr int G8_ST = 4;                        // stages of the ring
-template <int NCW>
-__global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, const int ntiles) {
-    constexpr int BN = 32 * NCW, AB = 24, BB = BN / 16;
+// NW = 8: one 512-thread workgroup per CU owns all 384 rows (four ring stages); NW = 4: a 256-thread workgroup owns HALF the rows (96
+// channels, gate and candidate) of the same tile with a three-stage ring of its own, TWO workgroups per CU: same waves per SIMD, same
+// wave tile, but the two workgroups are not in step - the gate epilogue of one (a third of a tile's time, pure vector work) runs
+// under the MFMAs of the other, and so do the issue slots its DMA pieces hold.
+template <int NCW, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bf16g_gate8_kernel(const GemmArgs a, const int ntiles) {
+    constexpr int BN = 32 * NCW, MW = NW / 2, AB = 6 * MW, BB = BN / 16, MH = 8 / NW, NST = NW == 8 ? 4 : 3;
+    constexpr int NBP = (BB + NW - 1) / NW, NP = 3 + NBP;                    // B pieces / all pieces of a stage per wave (at most)
     constexpr unsigned STB = (unsigned)(AB + BB) * 1024u;
     constexpr unsigned OOB = 0x80000000u;
+    static_assert(NP <= 6, "one piece per MFMA row");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];     // ALL LDS of the kernel is this one block
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6), wm = w >> 1, wn = w & 1;
@@ -374,64 +379,70 @@ __global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, cons
     // the four 16-lane groups a ds_read_b128 is served in (MI355X_MICROARCH.md, LDS table)
     const int dr = lane >> 2, dk = ((lane & 3) ^ ((0x1320 >> (4 * (dr >> 2))) & 3)) * 8;       // G8_SW = {0, 2, 3, 1}
     const unsigned rdl = (unsigned)(64 * n + 16 * (g4 ^ ((0x1320 >> (4 * (n >> 2))) & 3)));
-    // XCD-aware order (workgroup id i runs on XCD i % 8): each XCD walks a contiguous range of time tiles
-    const int chunk = (ntiles + 7) / 8;
-    const int gt = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= chunk || gt >= ntiles) return;
+    // XCD-aware order (workgroup id i runs on XCD i % 8): each XCD walks a contiguous range of time tiles, the row halves of a tile
+    // back to back (they stage the same activations)
+    const int nwork = ntiles * MH, chunk = (nwork + 7) / 8;
+    const int gw = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+    if ((int)(blockIdx.x >> 3) >= chunk || gw >= nwork) return;
+    const int gt = gw / MH, cb = (gw - gt * MH) * 48 * MW;                   // time tile, first channel of this workgroup
     const int b = gt / a.ntt, t0 = (gt - b * a.ntt) * BN;
     const int H = a.H;
     const g8_v4i rA = g8_rsrc(a.A, (size_t)a.M * a.Kd * 2), rB = g8_rsrc(a.src, a.src_bytes);
-    // A pieces of this wave: blocks w, w + 8, w + 16 (block q = tile rows 16 q ..: wave q / 6, fragment q % 6)
+    // A pieces of this wave: blocks w, w + NW, w + 2 NW (block q = tile rows 16 q ..: wave row q / 6, fragment q % 6)
     unsigned avo[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int q = w + 8 * j, qm = q / 6, qi = q - 6 * qm;
-        const int row = (qi & 1) * H + 48 * qm + 16 * (qi >> 1) + dr;
+        const int q = w + NW * j, qm = q / 6, qi = q - 6 * qm;
+        const int row = (qi & 1) * H + cb + 48 * qm + 16 * (qi >> 1) + dr;
         avo[j] = (unsigned)(((size_t)row * a.Kd + dk) * 2);
     }
-    // B pieces: block w, and block 8 + w on the waves below BB - 8
-    const bool two = BB > 8 && w < BB - 8;
-    int btl[2]; int bvo[2];
+    // B pieces: blocks w + NW j below BB
+    const int nbp = (BB - w + NW - 1) / NW;                                   // of this wave (wave-uniform)
+    int btl[NBP]; int bvo[NBP];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        btl[j] = t0 + 16 * (w + 8 * j) + dr;
+    for (int j = 0; j < NBP; ++j) {
+        btl[j] = t0 + 16 * (w + NW * j) + dr;
         bvo[j] = (int)((((size_t)b * a.Tp + btl[j]) * H + dk) * 2);
     }
     const int kpb = a.KB / 32, nk = a.nblk * kpb;
-    // one piece of stage kt (pc = 0..2: A, 3 / 4: B); the pieces of a stage are issued BETWEEN the MFMA rows of the stage in progress:
+    auto slot = [&](const int kt) -> unsigned { return (unsigned)(NST == 4 ? (kt & 3) : kt % 3) * STB; };
+    // one piece of stage kt (pc = 0..2: A, 3..: B); the pieces of a stage are issued BETWEEN the MFMA rows of the stage in progress:
     // a piece holds its wave's issue for 60-180 cycles (MI355X_MICROARCH.md, cycle constants), which the other wave of the SIMD
-    // fills with its MFMAs only if the pieces are not all issued at once behind the barrier, where both waves stand
+    // fills with its MFMAs only if the pieces are not all issued at once behind the barrier, where both waves stand.
+    // Stages past the end are issued all out-of-range (zeros into a free slot): the vmcnt arithmetic never changes.
     int iblk = 0, ikin = 0;                      // block (tap) and channel offset of the stage being issued
     auto piece = [&](const int kt, const int pc) __attribute__((always_inline)) {
-        const unsigned base = (unsigned)(kt & (G8_ST - 1)) * STB;
+        const unsigned base = slot(kt);
         const bool live = kt < nk;
-        if (pc < 3) { g8_dma(rA, live ? avo[pc] : OOB, live ? (unsigned)kt * 64u : 0u, base + (unsigned)(w + 8 * pc) * 1024u); return; }
+        if (pc < 3) { g8_dma(rA, live ? avo[pc] : OOB, live ? (unsigned)kt * 64u : 0u, base + (unsigned)(w + NW * pc) * 1024u); return; }
+        const int jb = pc - 3;
         const int shift = a.shift0 - iblk * a.shift_step;
         const int sk = (int)(((long)iblk * (long)a.blk_stride + (long)ikin - (long)shift * H) * 2);
-        if (pc == 3) g8_dma(rB, (live && btl[0] >= shift) ? (unsigned)(bvo[0] + sk) : OOB, 0u, base + (unsigned)(AB + w) * 1024u);
-        else {
-            if (two) g8_dma(rB, (live && btl[1] >= shift) ? (unsigned)(bvo[1] + sk) : OOB, 0u, base + (unsigned)(AB + 8 + w) * 1024u);
-            ikin += 32; if (ikin >= a.KB) { ikin = 0; ++iblk; }
-        }
-    };
-    auto issue = [&](const int kt) __attribute__((always_inline)) {
-#pragma unroll
-        for (int pc = 0; pc < 5; ++pc) piece(kt, pc);
+        if (jb < nbp) g8_dma(rB, (live && btl[jb] >= shift) ? (unsigned)(bvo[jb] + sk) : OOB, 0u, base + (unsigned)(AB + w + NW * jb) * 1024u);
+        if (jb == NBP - 1) { ikin += 32; if (ikin >= a.KB) { ikin = 0; ++iblk; } }
     };
     f32x4 acc[6][NCW];
 #pragma unroll
     for (int i = 0; i < 6; ++i)
 #pragma unroll
         for (int j = 0; j < NCW; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    issue(0); issue(1); issue(2);
+#pragma unroll
+    for (int kt = 0; kt < NST - 1; ++kt)
+#pragma unroll
+        for (int pc = 0; pc < NP; ++pc) piece(kt, pc);
     const unsigned rd_a = (unsigned)(6 * wm) * 1024u + rdl, rd_b = (unsigned)(AB + NCW * wn) * 1024u + rdl;
+    const int inflight = (3 + nbp) * (NST - 2);  // my pieces of the younger stages that may stay in flight
     for (int kt = 0; kt < nk; ++kt) {
-        // my pieces of stage kt have landed (two younger stages of 5 / 4 pieces stay in flight) ...
-        if (two) asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        // my pieces of stage kt have landed (the younger stages stay in flight) ...
+        if (inflight == 10) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+        else if (inflight == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (inflight == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (inflight == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // ... and my fragment reads of stage kt - 1 are back
-        __builtin_amdgcn_s_barrier();                            // everybody's: stage kt readable, slot (kt - 1) & 3 free
+        __builtin_amdgcn_s_barrier();                            // everybody's: stage kt readable, the slot of stage kt - 1 free
         asm volatile("" ::: "memory");
-        const unsigned char* sb = lds + (unsigned)(kt & (G8_ST - 1)) * STB;
+        const unsigned char* sb = lds + slot(kt);
         bf16x8 af[6], bfr[NCW];
 #pragma unroll
         for (int j = 0; j < NCW; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + rd_b + j * 1024);
@@ -441,9 +452,9 @@ __global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, cons
         for (int i = 0; i < 6; ++i) {
 #pragma unroll
             for (int j = 0; j < NCW; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-            if (i < 5) {                                         // stage kt + 3 goes into the slot the barrier has just freed
+            if (i < NP) {                                        // stage kt + NST - 1 goes into the slot the barrier has just freed
                 __builtin_amdgcn_sched_barrier(0);
-                piece(kt + 3, i);
+                piece(kt + NST - 1, i);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -457,12 +468,12 @@ __global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, cons
 #pragma unroll
             for (int j = 0; j < NCW; ++j) sum += acc[i][j];
         const int t = t0 + 16 * NCW * wn + n;
-        if (t < a.Tp) *reinterpret_cast<uint2*>(a.hnext + ((size_t)b * a.Tp + t) * H + 48 * wm + 4 * g4) = make_uint2(__float_as_uint(sum[0] + sum[1]), __float_as_uint(sum[2] + sum[3]));
+        if (t < a.Tp) *reinterpret_cast<uint2*>(a.hnext + ((size_t)b * a.Tp + t) * H + cb + 48 * wm + 4 * g4) = make_uint2(__float_as_uint(sum[0] + sum[1]), __float_as_uint(sum[2] + sum[3]));
         return;
     }
 #endif
-    // ---- gate epilogue: accumulator (i, j, r) = row 96 wm + 16 i + 4 g4 + r (i even: gate, odd: candidate of channels
-    // 48 wm + 16 (i >> 1) + 4 g4 + r), position t0 + 16 NCW wn + 16 j + n
+    // ---- gate epilogue: accumulator (i, j, r) = tile row 96 wm + 16 i + 4 g4 + r (i even: gate, odd: candidate of channels
+    // cb + 48 wm + 16 (i >> 1) + 4 g4 + r), position t0 + 16 NCW wn + 16 j + n
     int fj[NCW], jj0[NCW];
 #pragma unroll
     for (int j = 0; j < NCW; ++j) {
@@ -471,7 +482,7 @@ __global__ __launch_bounds__(512) void bf16g_gate8_kernel(const GemmArgs a, cons
     }
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
-        const int ch = 48 * wm + 16 * p + 4 * g4;
+        const int ch = cb + 48 * wm + 16 * p + 4 * g4;
         constexpr int JB = 2;                        // positions per batch of loads (three spill beside the 144 accumulator registers)
 #pragma unroll
         for (int j0 = 0; j0 < NCW; j0 += JB)
@@ -617,26 +628,32 @@ void launch_gemm(GemmArgs a, int ntt, int nmt, int batch, hipStream_t st) {
 }
 
 // the LDS-DMA gated layer (M = 384): tile width by fewer wasted rounds over the CUs; false = not launched (attribute refused)
+template <int NCW, int NW>
+bool launch_gate8_as(GemmArgs a, int batch, hipStream_t st) {
+    constexpr int BN = 32 * NCW, NST = NW == 8 ? 4 : 3;
+    constexpr size_t ldsb = (size_t)NST * (3 * NW + BN / 16) * 1024;
+    static bool attr_ok = false;
+    if (!attr_ok) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(bf16g_gate8_kernel<NCW, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) {
+            (void)hipGetLastError(); return false;
+        }
+        attr_ok = true;
+    }
+    a.ntt = (a.Tp + BN - 1) / BN; a.nmt = 1;
+    const int ntiles = a.ntt * batch, chunk = (ntiles * (8 / NW) + 7) / 8;
+    hipLaunchKernelGGL((bf16g_gate8_kernel<NCW, NW>), dim3((unsigned)(8 * chunk)), dim3(64 * NW), ldsb, st, a, ntiles);
+    return true;
+}
 bool launch_gate8(GemmArgs a, int batch, hipStream_t st) {
-    static int ncu = 0; static bool attr_ok[2] = {false, false};
+    static int ncu = 0;
     if (!ncu) {
         int dev = 0; hipDeviceProp_t pr;
         ncu = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
     }
+    if (a.cond && (size_t)batch * a.Tf * a.N * 4 >= (1ull << 31)) return false;
     auto rounds_cost = [&](int bn) { const long tiles = (long)batch * ((a.Tp + bn - 1) / bn); return ((tiles + ncu - 1) / ncu) * bn; };
-    const bool wide = rounds_cost(192) <= rounds_cost(128);
-    const int bn = wide ? 192 : 128;
-    const size_t ldsb = (size_t)G8_ST * (24 + bn / 16) * 1024;
-    const void* fn = wide ? reinterpret_cast<const void*>(bf16g_gate8_kernel<6>) : reinterpret_cast<const void*>(bf16g_gate8_kernel<4>);
-    if (!attr_ok[wide]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess) { (void)hipGetLastError(); return false; }
-        attr_ok[wide] = true;
-    }
-    a.ntt = (a.Tp + bn - 1) / bn; a.nmt = 1;
-    const int ntiles = a.ntt * batch, chunk = (ntiles + 7) / 8;
-    if (wide) hipLaunchKernelGGL(bf16g_gate8_kernel<6>, dim3((unsigned)(8 * chunk)), dim3(512), ldsb, st, a, ntiles);
-    else hipLaunchKernelGGL(bf16g_gate8_kernel<4>, dim3((unsigned)(8 * chunk)), dim3(512), ldsb, st, a, ntiles);
-    return true;
+    // two half-row workgroups per CU (NW = 4); the 512-thread form (NW = 8) measured 3 % slower (REF6 forward 1.244 against 1.208 ms)
+    return rounds_cost(192) <= rounds_cost(128) ? launch_gate8_as<6, 4>(a, batch, st) : launch_gate8_as<4, 4>(a, batch, st);
 }
 
 }  // namespace
