@@ -151,7 +151,7 @@ def cpu_model() -> str:
     return platform.processor() or "unknown"
 
 
-def _hip_timed(fn, reps: int, warm: int = 1):
+def _hip_timed(fn, reps: int, warm: int = 1, always_median: bool = False):
     """mean ms per call over `reps` back-to-back calls, HIP events on torch's current stream (the stream every launch
     helper uses).  A block that takes under 50 ms is measured three times and the median block is reported: one host
     hiccup between two launches (an allocator refill, a page fault) otherwise lands whole in a 10-call mean (seen once:
@@ -170,7 +170,7 @@ def _hip_timed(fn, reps: int, warm: int = 1):
         return e0.elapsed_time(e1)
 
     t = block()
-    if t < 50.0:
+    if t < 50.0 or always_median:
         t = sorted([t, block(), block()])[1]
     return t / reps
 
@@ -248,7 +248,9 @@ def decode_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, fs: int, reps:
     host_noise_s = time.perf_counter() - t0
     noise = noise.to(dev)
     cond = net.frontend(aux)
-    ms = _hip_timed(lambda: net.decode(aux, n_steps, noise, cond=cond, variant=variant), reps, warm=1)
+    # (the launch-chain decodes of the steady-state legs are paced by the dispatch path: a slope is the difference of two such
+    #  timings, so both are medians of three blocks - one driver run read 49 us per step where every other run reads 33-38)
+    ms = _hip_timed(lambda: net.decode(aux, n_steps, noise, cond=cond, variant=variant), reps, warm=1, always_median=steady)
     samples = B * n_steps * seg
     positions = n_steps + (cfg.receptive_field - seg + 1) // seg
     bpp = algorithmic_bytes_per_position(cfg, B)
@@ -263,7 +265,8 @@ def decode_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, fs: int, reps:
         # short utterance: the rf-position prologue weighs on the figure above; the per-step cost of a long utterance is
         # the slope between this decode and one of half the length (same launch chain, same prologue)
         half = n_steps // 2
-        ms_half = _hip_timed(lambda: net.decode(aux, half, noise[:, :half].contiguous(), cond=cond, variant=variant), reps, warm=1)
+        ms_half = _hip_timed(lambda: net.decode(aux, half, noise[:, :half].contiguous(), cond=cond, variant=variant), reps, warm=1,
+                             always_median=True)
         us = (ms - ms_half) * 1e3 / (n_steps - half)
         leg["steady_state_us_per_step"] = round(us, 3)
         leg["steady_state_real_time_factor"] = round(seg / (us * 1e-6) / fs, 2)
