@@ -131,8 +131,9 @@ def continuous_f0(f0) -> Tuple[np.ndarray, np.ndarray]:
 def noise_shaping(x, mean_mcep, fs: int, alpha: float, mag: float = 0.5, mcep_dim_start: int = 5, inv: bool = False,
                   shiftms: float = 5.0, cutoff: float = 70.0) -> np.ndarray:
     """one utterance of noise_shaping.py:144-181: the time-invariant MLSA filter built from the corpus-mean mel-cepstrum (the
-    statistics vector from `mcep_dim_start` on, scaled by `mag`, c(0) zeroed, sign flipped for the inverse filter of stage 9),
-    then the 70 Hz low cut."""
+    statistics vector from `mcep_dim_start` on, scaled by `mag`, c(0) zeroed; `inv` flips the sign of c(1..): run.sh APPLIES the shaping
+    with `--inv true` before training (run.sh:529-543) and RESTORES decoded waveforms with `--inv false` (run.sh:725-740)), then the
+    70 Hz low cut."""
     x = np.asarray(x, dtype=np.float64)
     coef = np.array(mean_mcep, dtype=np.float64)[mcep_dim_start:] * mag
     coef[0] = 0.0

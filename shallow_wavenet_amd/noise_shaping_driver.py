@@ -1,6 +1,7 @@
 """Stages 3 / 6 / 9 of run.sh - counterpart of `src/bin/noise_shaping.py` (same flags): every waveform of a directory or list is
-filtered with the time-invariant MLSA filter built from the corpus-mean mel-cepstrum (`--inv 1`: the inverse filter that restores a
-decoded waveform) and written as 16-bit PCM under `--writedir`.  Arithmetic: shallow_wavenet_amd/dsp.py (csrc/swn_dsp.c); the
+filtered with the time-invariant MLSA filter built from the corpus-mean mel-cepstrum (`--inv true`: coefficients negated - how
+run.sh:529-543 applies the shaping; `--inv false`: how run.sh:725-740 restores a decoded waveform) and written as 16-bit PCM under
+`--writedir`.  Arithmetic: shallow_wavenet_amd/dsp.py (csrc/swn_dsp.c); the
 statistics file is read through featio (HDF5 when h5py is present, the .npz side format otherwise)."""
 from __future__ import annotations
 
