@@ -77,6 +77,19 @@ __device__ __forceinline__ GateCh gate_consts(const GemmArgs& a, const int ch) {
     k.bdc = *reinterpret_cast<const float4*>(a.P + a.o_bd + (size_t)a.l * H2 + H + ch);
     return k;
 }
+// conditioning frame and upsampler tap of the positions tt, tt + 16, ...: ONE integer division (~30 instructions), the others by
+// stepping (a lane of the 384-row kernel had six of them per tile)
+template <int NJ>
+__device__ __forceinline__ void gate_frames(const int tt, const int U, int (&fj)[NJ], int (&jj0)[NJ]) {
+    int f = tt / U, jj = tt - f * U;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        fj[j] = f; jj0[j] = jj;
+        jj += 16;
+        while (jj >= U) { jj -= U; ++f; }
+    }
+}
+
 // One channel group (4 channels from ch) at NJ positions tb, tb + 16, ...: EVERY operand load of the group is issued before the
 // first store - written position by position, each store to hnext stood between the next position's loads and their use (the
 // compiler cannot know that hnext aliases none of them), i.e. one memory round trip per position and group: 18 in a row for a lane
@@ -271,11 +284,7 @@ __global__ __launch_bounds__(256, 3) void bf16g_gemm_kernel(const GemmArgs a) {
         // (inside the position loop every store to hnext stood between them and their reuse), and the conditioning frame of a
         // position comes from one division per position, not one per (position, group, segment tap).
         int fj[WNT], jj0[WNT];
-#pragma unroll
-        for (int j = 0; j < WNT; ++j) {
-            const int tt = t0 + 16 * WNT * wn + 16 * j + n + a.coff;
-            fj[j] = tt / a.U; jj0[j] = tt - fj[j] * a.U;
-        }
+        gate_frames<WNT>(t0 + 16 * WNT * wn + n + a.coff, a.U, fj, jj0);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int ch = by * 64 + 32 * wm + 16 * p + 4 * g4;          // 4 consecutive channels ch..ch+3
@@ -475,11 +484,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 2 : 1) void bf16g_gate8_kernel(c
     // ---- gate epilogue: accumulator (i, j, r) = tile row 96 wm + 16 i + 4 g4 + r (i even: gate, odd: candidate of channels
     // cb + 48 wm + 16 (i >> 1) + 4 g4 + r), position t0 + 16 NCW wn + 16 j + n
     int fj[NCW], jj0[NCW];
-#pragma unroll
-    for (int j = 0; j < NCW; ++j) {
-        const int tt = t0 + 16 * NCW * wn + 16 * j + n + a.coff;
-        fj[j] = tt / a.U; jj0[j] = tt - fj[j] * a.U;
-    }
+    gate_frames<NCW>(t0 + 16 * NCW * wn + n + a.coff, a.U, fj, jj0);
 #pragma unroll
     for (int p = 0; p < 3; ++p) {
         const int ch = cb + 48 * wm + 16 * p + 4 * g4;
