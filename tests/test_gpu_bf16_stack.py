@@ -49,6 +49,26 @@ def test_bf16_unsupported_geometry_is_reported(gpu_ok):
         net.forward_bf16(torch.zeros(1, cfg.n_aux, 4), torch.zeros(1, 1, 4 * cfg.U - 1))
 
 
+@pytest.mark.parametrize("seg,lpc,B,Tf", [(1, 4, 8, 38), (5, 4, 8, 38), (1, 4, 3, 130)])
+def test_lds_dma_gated_layer_wide_tiles(gpu_ok, seg, lpc, B, Tf):
+    """`bf16g_gate8_kernel` (the LDS-DMA gated layer of the H = 192 geometry) at sizes where its launcher takes the 192-position
+    tile (8 x 38 frames: 264 tiles of 128 are two rounds over the CUs, 176 tiles of 192 are one) - the small cases of the test
+    below run the 128-position form - with utterance ends inside a tile, seg = 5 conditioning taps crossing frame boundaries, and a
+    batch whose tile count is odd.  Outputs against the fp32 parity kernels at the usual 3e-3 of the output scale (every level of the
+    stack feeds them through skip)."""
+    cfg = C.ref6_laplace(seg, lpc)
+    sd = synth_state_dict(cfg, seed=6, flavor="trained")
+    net = HipNet.from_state_dict(cfg, sd, "cuda:0")
+    aux = torch.from_numpy(synth_aux(cfg, B, Tf))
+    T = Tf * cfg.U
+    audio = torch.rand(B, 1, T - seg, generator=torch.Generator().manual_seed(2)) * 1.6 - 0.8
+    r32, _ = net.forward(aux, audio)
+    r16 = net.forward_bf16(aux, audio)
+    d = (r32 - r16).abs()
+    assert float(d.max()) <= 3e-3 * max(1.0, float(r32.abs().max())), float(d.max())
+    assert float(d.mean()) <= 3e-4 * max(1.0, float(r32.abs().max()))
+
+
 @pytest.mark.parametrize("seg,lpc,B,Tf", [(1, 4, 2, 9), (5, 4, 1, 7)])
 def test_bf16_gemm_stack_for_large_geometries_tracks_the_fp32_kernels(gpu_ok, seg, lpc, B, Tf):
     """reference run.sh geometry (H=192, K=7, 3x2 layers: csrc/swn_stack_bf16g.hip) against the fp32 parity kernels:
