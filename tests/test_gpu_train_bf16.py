@@ -117,11 +117,12 @@ def test_softmax_gradients_bf16_mode(gpu_ok, name):
     _close(name, out["bf16"], out["fp32"])
 
 
-@pytest.mark.parametrize("shape", ["bl6", "ref6"])
+@pytest.mark.parametrize("shape", ["bl6", "ref6", "ref6_wide"])
 def test_full_size_gradients_bf16_mode(gpu_ok, shape):
-    """BASELINE cfg4-like chunk (4 x 20 frames) at the full BL6 / run.sh geometries: ragged tiles, K=7 taps."""
+    """BASELINE cfg4-like chunk (4 x 20 frames) at the full BL6 / run.sh geometries: ragged tiles, K=7 taps.  `ref6_wide`: a batch
+    at which the LDS-DMA gated layer takes its 192-position tiles (8 x 38 frames) with the pre-activations kept for the backward."""
     cfg = C.bl6_laplace(1, 0) if shape == "bl6" else C.ref6_laplace(1, 4)
-    B, Tf = 3, 12
+    B, Tf = (8, 38) if shape == "ref6_wide" else (3, 12)
     m = mc.CSWNV(**cfg.ctor_kwargs())
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True).items()})
     m.cuda().train()
@@ -208,14 +209,14 @@ def test_dropout_gradients_bf16_mode(gpu_ok, name):
     _close(name, got, ref, tol=6e-2, floor=5e-5)
 
 
-@pytest.mark.parametrize("shape", ["bl6", "ref6"])
+@pytest.mark.parametrize("shape", ["bl6", "ref6", "ref6_wide"])
 def test_full_size_dropout_step_bf16_mode(gpu_ok, shape):
     """dropout mode (do_prob = 0.5, forward(do=True): how run.sh trains) at the full BL6 / run.sh geometries, same masks in
     both modes: the mixed-precision mode runs the gated layers and the wide head layers of the forward on bf16 operands
     and hands the gate pre-activations to the backward; against the fp32 mode of the same kernels, 5e-2 per tensor like
     the step without dropout."""
     cfg = C.bl6_laplace(1, 0) if shape == "bl6" else C.ref6_laplace(1, 4)
-    B, Tf = 3, 12
+    B, Tf = (8, 38) if shape == "ref6_wide" else (3, 12)       # ref6_wide: the gated layers run on 192-position tiles
     m = mc.CSWNV(**cfg.ctor_kwargs(), do_prob=0.5)
     m.dropout_source = "host"            # the same masks for both modes
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(cfg, seed=3, flavor="trained", identity_scale_in=True).items()})
