@@ -357,7 +357,9 @@ def test_loss_curves_of_the_arithmetic_modes_track_each_other(gpu_ok, geom):
         m.cuda().train()
         for p in m.scale_in.parameters():
             p.requires_grad = False
-        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-3)
+        # (lr 2e-4: at 1e-3 the REF6 loss falls 20x in these 20 steps and the trajectories of the modes - and of two runs of one mode, through
+        #  the float atomics of the weight gradients - spread to within 10 % of the tolerance below; here they agree to 3 % of the final loss)
+        opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=2e-4)
         losses = []
         with train_precision(mode):
             for _ in range(N):
