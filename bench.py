@@ -332,7 +332,8 @@ def train_leg(name: str, cfg: C.NetConfig, dev, B: int, Tf: int, mode: str, reps
     m.to(dev).train()
     for p in m.scale_in.parameters():
         p.requires_grad = False
-    opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+    from shallow_wavenet_amd.train_driver import make_adam
+    opt = make_adam([p for p in m.parameters() if p.requires_grad], 1e-4)      # as the training drivers build it (fused on a GPU)
     T = Tf * cfg.U
     Tp = T - 2 * cfg.seg + 1
     aux = torch.from_numpy(synth_aux(cfg, B, Tf, seed=7)).to(dev)

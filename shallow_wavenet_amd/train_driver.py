@@ -98,6 +98,16 @@ def chunk_plan(n_frames: int, receptive_field: int, batch_size: int, seg: int, u
     return out
 
 
+def make_adam(params, lr: float):
+    """torch.optim.Adam as the reference constructs it (train_cswnv...py:456: default betas / eps, no weight decay), in torch's single-
+    launch `fused` form when every parameter lives on a GPU: the same update rule in one kernel instead of four multi-tensor passes
+    over the 51 parameter tensors (BL6 step 1.49 -> 1.36 ms; the optimizer's state_dict is interchangeable with the default form)."""
+    params = list(params)
+    flat = [q for p in params for q in (p["params"] if isinstance(p, dict) else [p])]
+    fused = len(flat) > 0 and all(q.is_cuda and q.is_floating_point() for q in flat)
+    return torch.optim.Adam(params, lr=lr, **({"fused": True} if fused else {}))
+
+
 def read_wav(path: str) -> np.ndarray:
     try:
         import soundfile as sf
@@ -443,7 +453,7 @@ def _run(args) -> int:
     set_scale_in(model, mean, scale)
     n_train = sum(int(np.prod(p.size())) for p in model.parameters() if p.requires_grad) / 1e6
     logging.info("Trainable Parameters: %.3f million" % n_train)
-    optimizer = torch.optim.Adam(optimizer_parameters(model), lr=args.lr)
+    optimizer = make_adam(optimizer_parameters(model), args.lr)
     epoch_idx = 0
     checkpoint = None
     if args.pretrained is not None:

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import artefacts
-from .train_driver import (_file_lists, read_feat, read_stats, read_wav, save_checkpoint, set_scale_in,
+from .train_driver import (_file_lists, make_adam, read_feat, read_stats, read_wav, save_checkpoint, set_scale_in,
                            synthetic_corpus, validate_length)
 
 
@@ -186,7 +186,7 @@ def _run(args) -> int:
     model.apply(initialize)
     set_scale_in(model, mean, scale)
     logging.info("Trainable Parameters: %.3f million" % (sum(int(np.prod(p.size())) for p in model.parameters() if p.requires_grad) / 1e6))
-    optimizer = torch.optim.Adam(optimizer_parameters(model), lr=args.lr)
+    optimizer = make_adam(optimizer_parameters(model), args.lr)
     epoch_idx, checkpoint = 0, None
     if args.pretrained is not None:
         checkpoint = artefacts.load_checkpoint(args.pretrained)
