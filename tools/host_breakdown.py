@@ -20,7 +20,8 @@ Tp = T - 2 * cfg.seg + 1
 tgt = (torch.rand(B, Tp, generator=torch.Generator().manual_seed(3)) * 1.8 - 0.9).cuda()
 for p in m.scale_in.parameters():
     p.requires_grad = False
-opt = torch.optim.Adam([p for p in m.parameters() if p.requires_grad], lr=1e-4)
+from shallow_wavenet_amd.train_driver import make_adam
+opt = make_adam([p for p in m.parameters() if p.requires_grad], 1e-4)
 acc = {}
 from shallow_wavenet_amd.nets import _autograd as _ag
 from shallow_wavenet_amd.runtime import HipNet
